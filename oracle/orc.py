@@ -1,0 +1,245 @@
+"""ctypes front-end for the two CPU oracles (oracle/orc_api.h).  TEST INFRASTRUCTURE ONLY.
+
+    Oracle("port")  -> oracle/_build/liboracle_port.so   our C++ restatement (oracle/cfr_oracle.cc)
+    Oracle("ref")   -> oracle/_ref/libref_driver.so       the unmodified reference behind the same API
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
+rebel_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(HERE, "_build", "liboracle_port.so")
+REF_LIB = os.path.join(HERE, "_ref", "libref_driver.so")
+
+NET_ZERO, NET_CALLBACK, NET_SYNTHETIC, NET_TORCHSCRIPT, NET_NONE = 0, 1, 2, 3, 4
+GET_AVERAGE, GET_LAST, GET_REGRETS, GET_SUM = 0, 1, 2, 3
+
+NET_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64)
+EX_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.POINTER(C.c_float), C.c_int64)
+
+
+class Params(C.Structure):
+    """Mirrors SubgameSolvingParams (/root/reference/csrc/liars_dice/subgame_solving.h:43-58)."""
+
+    _fields_ = [
+        ("num_iters", C.c_int32),
+        ("max_depth", C.c_int32),
+        ("linear_update", C.c_int32),
+        ("use_cfr", C.c_int32),
+        ("optimistic", C.c_int32),
+        ("dcfr", C.c_int32),
+        ("dcfr_alpha", C.c_double),
+        ("dcfr_beta", C.c_double),
+        ("dcfr_gamma", C.c_double),
+    ]
+
+
+def make_params(num_iters=10, max_depth=2, linear_update=False, use_cfr=False, optimistic=False, dcfr=False,
+                dcfr_alpha=0.0, dcfr_beta=0.0, dcfr_gamma=0.0):
+    return Params(num_iters, max_depth, int(linear_update), int(use_cfr), int(optimistic), int(dcfr), dcfr_alpha,
+                  dcfr_beta, dcfr_gamma)
+
+
+def build_port():
+    subprocess.check_call(["make", "-s", "-C", HERE, "port"])
+
+
+def have_ref():
+    return os.path.exists(REF_LIB)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Oracle:
+    def __init__(self, which="port"):
+        if which == "port":
+            if not os.path.exists(PORT_LIB):
+                build_port()
+            path = PORT_LIB
+        elif which == "ref":
+            path = REF_LIB
+            if not os.path.exists(path):
+                raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+            import torch  # noqa: F401  (libref_driver.so links libtorch; importing torch first resolves it)
+        else:
+            raise ValueError(which)
+        self.which = which
+        L = self.lib = C.CDLL(path)
+        L.orc_impl_name.restype = C.c_char_p
+        L.orc_solver_create.restype = C.c_void_p
+        L.orc_solver_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(Params), C.c_int, NET_FN, C.c_void_p,
+                                        C.c_char_p, EX_FN, C.c_void_p]
+        for name in ("orc_solver_destroy", "orc_solver_multistep", "orc_solver_update_value_network"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = None
+        L.orc_solver_tree_size.argtypes = [C.c_void_p]
+        L.orc_solver_step.argtypes = [C.c_void_p, C.c_int]
+        L.orc_solver_step.restype = None
+        L.orc_solver_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.orc_solver_get.restype = None
+        L.orc_solver_hand_values.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+        L.orc_solver_hand_values.restype = None
+        L.orc_rl_run.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int,
+                                 NET_FN, C.c_void_p, C.c_char_p, EX_FN, C.c_void_p]
+        L.orc_rl_run.restype = None
+        L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
+                                        C.c_int]
+        L.orc_synthetic_net.restype = None
+
+    # ---- game rules
+    def impl_name(self):
+        return self.lib.orc_impl_name().decode()
+
+    def num_actions(self, d, f):
+        return self.lib.orc_num_actions(d, f)
+
+    def num_hands(self, d, f):
+        return self.lib.orc_num_hands(d, f)
+
+    def num_matches(self, d, f, hand, face):
+        return self.lib.orc_num_matches(d, f, hand, face)
+
+    def unpack_action(self, d, f, action):
+        q, fc = C.c_int(), C.c_int()
+        self.lib.orc_unpack_action(d, f, action, C.byref(q), C.byref(fc))
+        return q.value, fc.value
+
+    def bid_range(self, d, f, last_bid):
+        lo, hi = C.c_int(), C.c_int()
+        self.lib.orc_bid_range(d, f, last_bid, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def unroll_tree(self, d, f, root_last_bid=-1, root_player=0, max_depth=2):
+        """-> int32[N,6] {last_bid, player_id, children_begin, children_end, parent, depth}"""
+        n = self.lib.orc_unroll_tree(d, f, root_last_bid, root_player, max_depth, None, 0)
+        out = np.zeros((n, 6), np.int32)
+        self.lib.orc_unroll_tree(d, f, root_last_bid, root_player, max_depth,
+                                 out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
+
+    def win_probability(self, d, f, bet, beliefs):
+        b = np.ascontiguousarray(beliefs, np.float64)
+        out = np.zeros(len(b))
+        self.lib.orc_compute_win_probability(d, f, bet, _dp(b), _dp(out))
+        return out
+
+    def get_query(self, d, f, traverser, last_bid, player, r0, r1):
+        r0 = np.ascontiguousarray(r0, np.float64)
+        r1 = np.ascontiguousarray(r1, np.float64)
+        out = np.zeros(2 + self.num_actions(d, f) + 2 * len(r0), np.float32)
+        self.lib.orc_get_query(d, f, traverser, last_bid, player, _dp(r0), _dp(r1), _fp(out))
+        return out
+
+    def normalize_safe(self, x, eps):
+        x = np.ascontiguousarray(x, np.float64)
+        od, of = np.zeros(len(x)), np.zeros(len(x), np.float32)
+        self.lib.orc_normalize_probabilities_safe(_dp(x), len(x), C.c_double(eps), _dp(od), _fp(of))
+        return od, of
+
+    def synthetic_net(self, queries, num_actions, num_hands):
+        q = np.ascontiguousarray(queries, np.float32)
+        out = np.zeros((q.shape[0], num_hands), np.float32)
+        self.lib.orc_synthetic_net(_fp(q), q.shape[0], q.shape[1], _fp(out), num_hands, num_actions)
+        return out
+
+    def exploitability2(self, d, f, strategy):
+        s = np.ascontiguousarray(strategy, np.float64)
+        out = np.zeros(2)
+        self.lib.orc_compute_exploitability2(d, f, _dp(s), _dp(out))
+        return out
+
+    # ---- solvers
+    def solver(self, d, f, params, root_last_bid=-1, root_player=0, beliefs=None, net=NET_ZERO, net_fn=None,
+               torchscript_path=None, on_example=None):
+        return OracleSolver(self, d, f, params, root_last_bid, root_player, beliefs, net, net_fn, torchscript_path,
+                            on_example)
+
+    def rl_run(self, d, f, params, seed, num_games, random_action_prob=0.25, sample_leaf=True, net=NET_ZERO,
+               net_fn=None, torchscript_path=None):
+        """Plays num_games self-play games (RlRunner::step); returns the emitted examples [(query, values)]."""
+        H, A = self.num_hands(d, f), self.num_actions(d, f)
+        examples = []
+
+        def _ex(_u, q, qs, v, vs):
+            examples.append((np.ctypeslib.as_array(q, (qs,)).copy(), np.ctypeslib.as_array(v, (vs,)).copy()))
+
+        cb_net = _wrap_net(net_fn, H) if net_fn is not None else NET_FN()
+        cb_ex = EX_FN(_ex)
+        self.lib.orc_rl_run(d, f, C.c_double(random_action_prob), int(sample_leaf), C.byref(params), seed, num_games,
+                            net, cb_net, None, (torchscript_path or "").encode(), cb_ex, None)
+        return examples
+
+
+def _wrap_net(fn, H):
+    def _cb(_u, q, rows, qs, out, osz):
+        qa = np.ctypeslib.as_array(q, (rows, qs))
+        res = np.ascontiguousarray(fn(qa.copy()), np.float32)
+        assert res.shape == (rows, osz), (res.shape, rows, osz)
+        np.ctypeslib.as_array(out, (rows, osz))[...] = res
+
+    return NET_FN(_cb)
+
+
+class OracleSolver:
+    def __init__(self, orc, d, f, params, root_last_bid, root_player, beliefs, net, net_fn, ts_path, on_example):
+        self.orc, self.d, self.f = orc, d, f
+        self.H, self.A = orc.num_hands(d, f), orc.num_actions(d, f)
+        if beliefs is None:
+            beliefs = np.full((2, self.H), 1.0 / self.H)
+        b = np.ascontiguousarray(beliefs, np.float64)
+        self._net_cb = _wrap_net(net_fn, self.H) if net_fn is not None else NET_FN()
+        self.examples = []
+
+        def _ex(_u, q, qs, v, vs):
+            ex = (np.ctypeslib.as_array(q, (qs,)).copy(), np.ctypeslib.as_array(v, (vs,)).copy())
+            self.examples.append(ex)
+            if on_example:
+                on_example(*ex)
+
+        self._ex_cb = EX_FN(_ex)
+        self._params = params
+        self.h = orc.lib.orc_solver_create(d, f, root_last_bid, root_player, _dp(b[0]), _dp(b[1]), C.byref(params),
+                                           net, self._net_cb, None, (ts_path or "").encode(), self._ex_cb, None)
+        self.N = orc.lib.orc_solver_tree_size(self.h)
+
+    def step(self, traverser):
+        self.orc.lib.orc_solver_step(self.h, traverser)
+
+    def multistep(self):
+        self.orc.lib.orc_solver_multistep(self.h)
+
+    def get(self, which):
+        out = np.zeros((self.N, self.H, self.A))
+        self.orc.lib.orc_solver_get(self.h, which, _dp(out))
+        return out
+
+    def hand_values(self, player):
+        out = np.zeros(self.H)
+        self.orc.lib.orc_solver_hand_values(self.h, player, _dp(out))
+        return out
+
+    def update_value_network(self):
+        self.orc.lib.orc_solver_update_value_network(self.h)
+
+    def close(self):
+        if self.h:
+            self.orc.lib.orc_solver_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

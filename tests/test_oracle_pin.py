@@ -1,0 +1,84 @@
+"""Pins the port oracle (oracle/cfr_oracle.cc) to the compiled, unmodified reference (oracle/_ref): bit-for-bit on
+every solver array and on self-play trajectories.  Skipped where the compiled reference is not available (then the
+committed golden vectors, generated from it, take over: tests/test_golden.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import orc
+from tests.cases import NET_CODE, RL_CASES, SOLVER_CASES, case_beliefs
+
+
+@pytest.mark.parametrize("name", sorted(SOLVER_CASES))
+def test_solver_bit_exact(name, port, ref):
+    c = SOLVER_CASES[name]
+    p = orc.make_params(**c["p"])
+    H = port.num_hands(c["d"], c["f"])
+    b = case_beliefs(c, H)
+    a = ref.solver(c["d"], c["f"], p, c.get("lb", -1), c.get("pl", 0), b, NET_CODE[c["net"]])
+    o = port.solver(c["d"], c["f"], p, c.get("lb", -1), c.get("pl", 0), b, NET_CODE[c["net"]])
+    assert a.N == o.N
+    checkpoints = {1, 2, 3, p.num_iters // 2, p.num_iters}
+    which = [orc.GET_AVERAGE, orc.GET_LAST, orc.GET_SUM] + ([orc.GET_REGRETS] if p.use_cfr else [])
+    for it in range(p.num_iters):
+        a.step(it % 2)
+        o.step(it % 2)
+        if it + 1 in checkpoints:
+            for w in which:
+                assert np.array_equal(a.get(w), o.get(w)), (name, it, w)
+            if it >= 1:
+                for pl in (0, 1):
+                    assert np.array_equal(a.hand_values(pl), o.hand_values(pl))
+    if c["net"] == "none":
+        return  # the reference dereferences its (null) net in update_value_network
+    a.update_value_network()
+    o.update_value_network()
+    assert len(a.examples) == len(o.examples) == 2
+    for (qa, va), (qo, vo) in zip(a.examples, o.examples):
+        assert np.array_equal(qa, qo) and np.array_equal(va, vo)
+
+
+@pytest.mark.parametrize("name", sorted(RL_CASES))
+def test_selfplay_trajectories_bit_exact(name, port, ref):
+    c = RL_CASES[name]
+    p = orc.make_params(**c["p"])
+    kw = dict(random_action_prob=c["rap"], sample_leaf=c["leaf"], net=NET_CODE[c["net"]])
+    a = ref.rl_run(c["d"], c["f"], p, c["seed"], c["games"], **kw)
+    o = port.rl_run(c["d"], c["f"], p, c["seed"], c["games"], **kw)
+    assert len(a) == len(o) and len(a) >= 2 * c["games"]
+    for (qa, va), (qo, vo) in zip(a, o):
+        assert np.array_equal(qa, qo) and np.array_equal(va, vo)
+
+
+def test_callback_net_teacher_forcing(port, ref):
+    """Both oracles driven by the SAME python callback net see identical queries and end bit-identical."""
+    d, f = 1, 6
+    A, H = port.num_actions(d, f), port.num_hands(d, f)
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal((2 + A + 2 * H, H)).astype(np.float32) * 0.3
+    seen = {"ref": [], "port": []}
+
+    def make(tag):
+        def fn(q):
+            seen[tag].append(q.copy())
+            return np.tanh(q @ W).astype(np.float32)
+        return fn
+
+    p = orc.make_params(num_iters=200, max_depth=2, linear_update=True, use_cfr=True)
+    a = ref.solver(d, f, p, net=orc.NET_CALLBACK, net_fn=make("ref"))
+    o = port.solver(d, f, p, net=orc.NET_CALLBACK, net_fn=make("port"))
+    a.multistep()
+    o.multistep()
+    assert len(seen["ref"]) == len(seen["port"]) == 200
+    for x, y in zip(seen["ref"], seen["port"]):
+        assert np.array_equal(x, y)
+    for w in (orc.GET_AVERAGE, orc.GET_LAST, orc.GET_SUM, orc.GET_REGRETS):
+        assert np.array_equal(a.get(w), o.get(w))
+
+
+def test_exploitability_matches(port, ref):
+    p = orc.make_params(num_iters=128, max_depth=100, linear_update=True, use_cfr=True)
+    s = ref.solver(1, 4, p, net=orc.NET_NONE)
+    s.multistep()
+    strat = s.get(orc.GET_AVERAGE)
+    assert np.array_equal(ref.exploitability2(1, 4, strat), port.exploitability2(1, 4, strat))
