@@ -1,0 +1,132 @@
+/* include/rebel_hip.h -- C ABI of librebel_hip.so, the MI355X (gfx950) engine for ReBeL self-play data generation on
+ * Liar's Dice.  Plain pointers and sizes only; no torch / pybind types.
+ *
+ * The reference (facebookresearch/rebel) has no C ABI: its seam is the pybind11 module `cfvpy.rela`
+ * (csrc/liars_dice/rela/pybind.cc:119-213) over the C++ interfaces ISubgameSolver / IValueNet / RlRunner.  Every
+ * entry point below names the reference interface it stands in for, so that a maintainer can bind it from the
+ * reference's pybind layer -- and `rebel_amd/csrc/rela_module.cc` is exactly that binding.
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success, non-zero on failure; rbl_last_error() holds the message
+ *     (thread-local).  Reference behaviour "throw std::runtime_error / assert" maps to a non-zero status.
+ *   - a `lane` is one independent subgame solver / self-play game (what one reference data-gen thread holds);
+ *     lanes [0, B) of an engine are advanced in lock-step by the same kernel launches.
+ *   - dense strategy layout on the boundary is the reference's TreeStrategy, double[N][H][A]
+ *     (subgame_solving.h:39); device-side layout is edge-indexed.
+ *   - host pointers unless the name says `_dev`.
+ */
+#ifndef REBEL_HIP_H_
+#define REBEL_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rbl_engine rbl_engine;     /* one GPU, one game (dice x faces), one set of solver params */
+typedef struct rbl_selfplay rbl_selfplay; /* a set of RlRunner lanes on an engine */
+
+/* SubgameSolvingParams (subgame_solving.h:43-58).  use_cfr must be 1 (the path north_star names); FP is rejected. */
+typedef struct {
+  int32_t num_iters, max_depth, linear_update, use_cfr, optimistic, dcfr;
+  double dcfr_alpha, dcfr_beta, dcfr_gamma;
+} rbl_params;
+
+/* Net2 weights (cfvpy/models.py:64-94): n_layers x [Linear(in,hid) -> LayerNorm(hid)? -> GELU] -> Linear(hid,out).
+ * All fp32, row-major [out][in] as torch.nn.Linear stores them.  ln_* may be NULL when use_layer_norm == 0. */
+typedef struct {
+  int32_t n_layers, n_in, n_hidden, n_out, use_layer_norm;
+  const float* const* w;    /* [n_layers]  w[l]: [n_hidden][l==0 ? n_in : n_hidden] */
+  const float* const* b;    /* [n_layers]  [n_hidden] */
+  const float* const* ln_w; /* [n_layers]  [n_hidden] */
+  const float* const* ln_b; /* [n_layers]  [n_hidden] */
+  const float* w_out;       /* [n_out][n_hidden] */
+  const float* b_out;       /* [n_out] */
+  float ln_eps;             /* torch default 1e-5 */
+} rbl_mlp_weights;
+
+/* IValueNet::compute_values (net_interface.h:28) as a callback: fill out[rows][n_out] from queries[rows][qsize].
+ * With host_buffers=1 the pointers are host memory (engine copies D2H/H2D around the call); with 0 they are device
+ * pointers on the engine's device and the callee must enqueue its work on `stream` (a hipStream_t). */
+typedef void (*rbl_net_fn)(void* user, const float* queries, int64_t rows, int64_t qsize, float* out, int64_t n_out,
+                           void* stream);
+/* IValueNet::add_training_example (net_interface.h:31-32), batched: n examples, lane ids for bookkeeping. */
+typedef void (*rbl_example_fn)(void* user, int64_t n, const int32_t* lanes, const float* queries, int64_t qsize,
+                               const float* values, int64_t n_out);
+
+enum { RBL_GET_AVERAGE = 0, RBL_GET_LAST = 1, RBL_GET_REGRETS = 2, RBL_GET_SUM = 3 };
+
+const char* rbl_last_error(void);
+int rbl_device_count(void);
+const char* rbl_build_info(void); /* "gfx950 hipcc <version> ..." */
+
+/* ---- game rules (liars_dice.h:46-155) and the BFS public tree (tree.h:51-70), host side, for callers/tests ---- */
+int rbl_num_actions(int dice, int faces);
+int rbl_num_hands(int dice, int faces);
+int rbl_query_size(int dice, int faces); /* get_query_size, subgame_solving.cc:100-102 */
+/* 6 ints per node {last_bid, player_id, children_begin, children_end, parent, depth}; returns N (fills min(N,cap)). */
+int rbl_unroll_tree(int dice, int faces, int root_last_bid, int root_player, int max_depth, int32_t* out, int cap_nodes);
+
+/* ---- engine ---- */
+rbl_engine* rbl_engine_create(int device, int dice, int faces, const rbl_params* params, int max_lanes);
+void rbl_engine_destroy(rbl_engine* e);
+void* rbl_engine_stream(rbl_engine* e); /* hipStream_t all engine work is enqueued on */
+
+/* value net selection (IValueNet implementations: real_net.cc:30-55 zero net; TorchScriptNet :57-87) */
+int rbl_engine_set_net_zero(rbl_engine* e);
+int rbl_engine_set_net_synthetic(rbl_engine* e); /* test double, elementwise; same formula as oracle/orc_api.h */
+int rbl_engine_set_net_mlp(rbl_engine* e, const rbl_mlp_weights* w); /* ModelLocker ctor/updateModel, model_locker.h:56-79 */
+int rbl_engine_set_net_callback(rbl_engine* e, rbl_net_fn fn, void* user, int host_buffers);
+
+/* standalone batched forward of the current net (ModelLocker::forward, model_locker.h:85-95) */
+int rbl_net_forward(rbl_engine* e, const float* queries, int64_t rows, float* out);          /* host in/out */
+int rbl_net_forward_dev(rbl_engine* e, const float* queries_dev, int64_t rows, float* out_dev); /* device, async */
+
+/* ---- batched subgame solver: build_solver (subgame_solving.cc:791-800) for B lanes at once ----
+ * root_last_bid[b] in [-1, A-1), root_player[b] in {0,1}, beliefs [B][2][H] (NOT re-normalised, as the reference).
+ * act_iteration may be NULL; if given, lane b's sigma_last after act_iteration[b] steps is kept for rbl_solver_get_snapshot. */
+int rbl_solver_reset(rbl_engine* e, int B, const int32_t* root_last_bid, const int32_t* root_player,
+                     const double* beliefs, const int32_t* act_iteration);
+int rbl_solver_step(rbl_engine* e, int traverser);  /* ISubgameSolver::step, CFR::step subgame_solving.cc:577-664 */
+int rbl_solver_multistep(rbl_engine* e, int n);     /* n steps, traverser = global_iter % 2 (:666-670); n<0: num_iters */
+int rbl_solver_sync(rbl_engine* e);                 /* wait for enqueued steps */
+int rbl_solver_num_lanes(rbl_engine* e);
+int rbl_solver_tree_size(rbl_engine* e, int lane);
+int64_t rbl_solver_total_rows(rbl_engine* e);       /* sum over lanes of pseudo-leaves = net rows per step */
+/* dense double[N][H][A]; which = RBL_GET_* (get_strategy / get_sampling_strategy :678-688; regrets, sum_strategies) */
+int rbl_solver_get(rbl_engine* e, int lane, int which, double* out);
+int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out); /* sigma_last at the lane's act_iteration */
+int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out); /* get_hand_values :694-696 */
+/* update_value_network (:672-676): writes the lane's two training examples, queries[2][Q], values[2][H] */
+int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values);
+/* last queries written for the net, for inspection: out[rows][Q]; rows = rbl_solver_total_rows */
+int rbl_solver_get_queries(rbl_engine* e, float* out);
+
+/* ---- self-play lanes: RlRunner (recursive_solving.h:40-86), one per seed (create_cfr_thread, pybind.cc:36-43) ---- */
+rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
+                                  int sample_leaf);
+void rbl_selfplay_destroy(rbl_selfplay* sp);
+/* Advances every lane by ONE subgame (num_iters CFR steps + sampling, recursive_solving.cc:166-181) and hands the
+ * 2*n_lanes training examples to `sink` in lane order.  Returns the number of subgame-CFR-iterations executed
+ * (n_lanes * num_iters) or -1 on error. */
+int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user);
+int64_t rbl_selfplay_games_finished(rbl_selfplay* sp);
+/* per-lane public state for inspection: last_bid, player_id (liars_dice.h:35-44) */
+int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id);
+
+/* ---- timing of the two dominant kernels since the last reset (HIP events on the engine stream) ---- */
+typedef struct {
+  double cfr_ms, net_ms;     /* summed kernel time */
+  int64_t cfr_launches, net_launches;
+  int64_t net_rows;          /* rows pushed through the net */
+  int64_t lane_steps;        /* subgame-CFR-iterations */
+  double cfr_bytes, net_flops; /* algorithmic bytes / flops of those launches (DESIGN.md formulas, per-lane shapes) */
+} rbl_kernel_stats;
+int rbl_engine_timing(rbl_engine* e, int enable); /* enable per-launch event timing (serialises; bench only) */
+int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REBEL_HIP_H_ */

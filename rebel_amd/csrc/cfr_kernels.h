@@ -1,0 +1,67 @@
+// rebel_amd/csrc/cfr_kernels.h -- launch interface of the batched CFR step kernel (cfr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tables.h"
+
+namespace rbl {
+
+enum CfrMode : int {
+  kModeInit = 0,     // build_solver: uniform sigma, zero regrets, reach-weighted sum; then write queries
+  kModeStep = 1,     // consume leaf values of the pending queries, CFR::step, then write the next queries
+  kModeQueries = 2,  // only (re)write queries for `next_trav` from the current sigma
+};
+
+// Everything the kernel needs; passed by value (fits the kernarg segment).
+struct CfrArgs {
+  // ---- static tables (per engine)
+  const ShapeDev* shapes;
+  const int* parent;
+  const int* act;
+  const int* cb;
+  const int* ce;
+  const int* depth;
+  const int* leaves;
+  const int* terms;
+  const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
+  int H, A, Q, faces, dice;
+  int Emax, Nmax;         // per-lane strides: Emax*H reals per strategy array
+  // ---- per-lane descriptors
+  const int* lane_shape;
+  const int* lane_root_player;
+  const int* lane_row_off;   // first net row of the lane
+  const int* lane_act_iter;  // snapshot when steps_after == act_iter (may be null)
+  const double* beliefs;     // [B][2][H]
+  // ---- per-lane state, edge-indexed [B][Emax*H]
+  double* sigma;     // last_strategies
+  double* regrets;
+  double* sums;      // sum_strategies
+  double* snapshot;  // sigma at act_iteration
+  double* root_mean; // [B][2][H] root_values_means
+  // ---- net exchange
+  float* queries;       // [rows][Q]
+  const float* values;  // [rows][H]
+  // ---- global scratch for lanes too big for LDS: [B][work_reals]
+  double* scratch;
+  size_t work_stride;
+  int use_lds;
+  // ---- uniform step parameters (lanes are in lock-step)
+  int mode, trav, next_trav, steps_after;
+  double alpha;            // root-mean step size (subgame_solving.cc:580-590)
+  double pos, neg, strat;  // discounts (:592-617)
+};
+
+// reals of per-lane working set: rho0, rho1, val [N][H], sigma [E][H], tmp
+inline size_t cfr_work_reals(int N, int H, int L, int T, int dice) {
+  const size_t tmp = (size_t)std::max(2 * L, L + T * (2 * dice + 2)) + 2;
+  return (size_t)3 * N * H + (size_t)(N - 1) * H + tmp;
+}
+
+// test double of the value net (oracle/orc_api.h: orc_synthetic_net); lives in the -ffp-contract=off TU
+void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream);
+
+void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
+
+}  // namespace rbl

@@ -1,0 +1,182 @@
+// rebel_amd/csrc/engine.h -- host side of the MI355X engine: device tables, lane state, step scheduling, self-play lanes.
+//
+// Mirrors, lane-batched, what one reference data-gen thread owns:
+//   Engine   ~ build_solver + ISubgameSolver (subgame_solving.h:60-88, subgame_solving.cc:791-800) for B subgames at once
+//   SelfPlay ~ RlRunner (recursive_solving.h:40-86, recursive_solving.cc:160-275), one RNG per lane
+// The C ABI in include/rebel_hip.h is a thin wrapper over these two classes (capi in engine.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rebel_hip.h"
+#include "cfr_kernels.h"
+#include "net_kernels.h"
+#include "tables.h"
+
+namespace rbl {
+
+#define RBL_HIP_CHECK(expr)                                                                                   \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess)                                                                                     \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " + __FILE__ + ":" + \
+                               std::to_string(__LINE__) + " (" #expr ")");                                    \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    RBL_HIP_CHECK(hipMalloc(&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const std::vector<T>& h, hipStream_t s) {
+    if (h.size() > n) alloc(h.size());
+    if (!h.empty()) RBL_HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+enum class NetMode { kZero, kSynthetic, kMlp, kCallback };
+
+class Engine {
+ public:
+  Engine(int device, int dice, int faces, const rbl_params& params, int max_lanes);
+  ~Engine();
+
+  // ---- value net
+  void set_net_zero();
+  void set_net_synthetic();
+  void set_net_mlp(const rbl_mlp_weights& w);
+  void set_net_callback(rbl_net_fn fn, void* user, bool host_buffers);
+  void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev);  // async on stream()
+  void net_forward_host(const float* q, int64_t rows, float* out);
+
+  // ---- batched solver
+  void reset(int B, const int32_t* root_last_bid, const int32_t* root_player, const double* beliefs,
+             const int32_t* act_iteration);
+  void step(int traverser);
+  void multistep(int n);
+  void sync();
+  int num_lanes() const { return B_; }
+  int tree_size(int lane) const;
+  int64_t total_rows() const { return rows_; }
+  void get(int lane, int which, double* out);
+  void get_snapshot(int lane, double* out);
+  void hand_values(int lane, int player, double* out);
+  void examples(int lane, float* queries, float* values);
+  void get_queries(float* out);
+
+  // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
+  void read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean);
+
+  void timing(bool enable);
+  void stats(rbl_kernel_stats* out, bool reset);
+
+  const Rules& rules() const { return g_; }
+  const rbl_params& params() const { return p_; }
+  const ShapeTables& tables() const { return tabs_; }
+  hipStream_t stream() const { return stream_; }
+  int emax() const { return emax_; }
+  int max_lanes() const { return max_lanes_; }
+  void write_root_query(int traverser, int last_bid, int player, const double* b0, const double* b1, float* q) const;
+
+ private:
+  void check_lane(int lane) const;
+  void run_net();
+  void launch(int mode, int trav, int next_trav, int steps_after, double alpha, double pos, double neg, double strat);
+  void expand_dense(int lane, const std::vector<double>& edge, double* out) const;
+  void read_lane(const double* dev_base, int lane, std::vector<double>* out);
+  struct Timed;
+  void time_begin(int kind);
+  void time_end(int kind);
+
+  int device_;
+  Rules g_;
+  rbl_params p_;
+  ShapeTables tabs_;
+  int max_lanes_, emax_, nmax_;
+  hipStream_t stream_ = nullptr;
+
+  DevBuf<ShapeDev> d_shapes_;
+  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_;
+  DevBuf<int8_t> d_matches_;
+  DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
+  DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
+  DevBuf<float> d_queries_, d_values_, d_mlp_blob_, d_tmp_q_, d_tmp_o_;
+
+  std::vector<int> h_shape_, h_player_, h_row_, h_act_, h_bid_;
+  std::vector<double> h_beliefs_;
+  int B_ = 0;
+  int64_t rows_ = 0;
+  bool has_act_ = false;
+  int iter_ = 0, num_steps_[2] = {0, 0}, pending_trav_ = -1;
+
+  NetMode net_mode_ = NetMode::kZero;
+  bool values_zeroed_ = false;
+  MlpDev mlp_;
+  rbl_net_fn cb_fn_ = nullptr;
+  void* cb_user_ = nullptr;
+  bool cb_host_ = true;
+  std::vector<float> h_q_, h_v_;
+
+  int block_ = 64;
+  size_t lds_bytes_ = 0, work_stride_ = 0;
+  bool use_lds_ = true;
+
+  // accounting
+  bool timing_ = false;
+  std::vector<hipEvent_t> ev_pool_;
+  struct Pending {
+    int kind;
+    size_t e0, e1;
+  };
+  std::vector<Pending> pending_;
+  size_t ev_used_ = 0;
+  rbl_kernel_stats stats_{};
+  double step_bytes_[2] = {0, 0};  // algorithmic bytes of one CFR step per traverser, summed over lanes
+};
+
+class SelfPlay {
+ public:
+  SelfPlay(Engine* e, int n_lanes, const int32_t* seeds, double random_action_prob, bool sample_leaf);
+  int64_t advance(rbl_example_fn sink, void* user);
+  int64_t games_finished() const { return games_; }
+  void state(int lane, int32_t* last_bid, int32_t* player) const;
+  int num_lanes() const { return n_; }
+
+ private:
+  void sample_to_leaf(int lane, const double* sigma);
+  void sample_single(int lane, const double* sigma);
+  void bayes(double* b, const double* sigma, int shape_node_off, int child, int H) const;
+
+  Engine* e_;
+  int n_;
+  float rap_;
+  bool leaf_;
+  std::vector<std::mt19937> gen_;
+  std::vector<int32_t> bid_, player_, act_;
+  std::vector<double> beliefs_;  // [n][2][H]
+  std::vector<double> snap_, rmean_;
+  std::vector<float> ex_q_, ex_v_;
+  std::vector<int32_t> ex_lane_;
+  int64_t games_ = 0;
+};
+
+}  // namespace rbl

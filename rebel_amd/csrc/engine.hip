@@ -1,0 +1,823 @@
+// rebel_amd/csrc/engine.hip -- Engine / SelfPlay implementation and the C ABI (include/rebel_hip.h).
+// Host code only (the kernels live in cfr_kernels.hip / net_kernels.hip); compiled with -ffp-contract=off because the
+// few fp64 formulas evaluated here (discounts, root queries, average strategy read-back, Bayes updates while
+// sampling) are part of the bit-exactness contract with the reference.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace rbl {
+
+namespace {
+
+constexpr double kEps = 1e-80;  // subgame_solving.h:34-36
+
+template <class T>
+void normalize_safe(const double* x, int n, double eps, T* out) {  // util.h:68-78
+  double sum = 0;
+  for (int i = 0; i < n; ++i) sum += x[i] + eps;
+  for (int i = 0; i < n; ++i) out[i] = (T)((x[i] + eps) / sum);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = std::getenv(name);
+  return s && *s ? std::atoi(s) : dflt;
+}
+
+}  // namespace
+
+// =================================================================================================== Engine
+Engine::Engine(int device, int dice, int faces, const rbl_params& params, int max_lanes)
+    : device_(device), g_(dice, faces), p_(params), max_lanes_(max_lanes) {
+  if (!p_.use_cfr) throw std::runtime_error("engine: only use_cfr=1 is implemented on the GPU path (FP solver is out of scope)");
+  if (p_.linear_update && p_.dcfr) throw std::runtime_error("engine: linear_update and dcfr are exclusive (subgame_solving.cc:533)");
+  if (p_.max_depth < 0) throw std::runtime_error("engine: max_depth must be >= 0");
+  if (max_lanes < 1) throw std::runtime_error("engine: max_lanes must be >= 1");
+  int ndev = 0;
+  RBL_HIP_CHECK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) throw std::runtime_error("engine: no such HIP device " + std::to_string(device));
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+
+  tabs_ = ShapeTables::build(g_, p_.max_depth);
+  nmax_ = tabs_.max_N;
+  emax_ = std::max(1, nmax_ - 1);
+
+  d_shapes_.upload(tabs_.shapes, stream_);
+  d_parent_.upload(tabs_.parent, stream_);
+  d_act_.upload(tabs_.act, stream_);
+  d_cb_.upload(tabs_.cb, stream_);
+  d_ce_.upload(tabs_.ce, stream_);
+  d_depth_.upload(tabs_.depth, stream_);
+  d_leaves_.upload(tabs_.leaves, stream_);
+  d_terms_.upload(tabs_.terms, stream_);
+  std::vector<int8_t> m((size_t)g_.faces * g_.H);
+  for (int f = 0; f < g_.faces; ++f)
+    for (int h = 0; h < g_.H; ++h) m[(size_t)f * g_.H + h] = (int8_t)g_.matches(h, f);
+  d_matches_.upload(m, stream_);
+
+  const size_t L = (size_t)max_lanes_;
+  const size_t eh = (size_t)emax_ * g_.H;
+  d_lane_shape_.alloc(L);
+  d_lane_player_.alloc(L);
+  d_lane_row_.alloc(L);
+  d_lane_act_.alloc(L);
+  d_beliefs_.alloc(L * 2 * g_.H);
+  d_sigma_.alloc(L * eh);
+  d_regrets_.alloc(L * eh);
+  d_sums_.alloc(L * eh);
+  d_snapshot_.alloc(L * eh);
+  d_root_mean_.alloc(L * 2 * g_.H);
+  const size_t max_rows = std::max<size_t>(1, L * tabs_.max_L);
+  d_queries_.alloc(max_rows * g_.query_size());
+  d_values_.alloc(max_rows * g_.H);
+  RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, max_rows * g_.H * sizeof(float), stream_));
+  values_zeroed_ = true;
+
+  // working set per lane: LDS if it fits in one CU's 160 KB with room for >= 2 workgroups, else global scratch
+  work_stride_ = cfr_work_reals(nmax_, g_.H, tabs_.max_L, tabs_.max_T, g_.dice);
+  lds_bytes_ = work_stride_ * sizeof(double);
+  const size_t lds_cap = (size_t)env_int("RBL_CFR_LDS_CAP", 80 * 1024);
+  use_lds_ = lds_bytes_ <= lds_cap;
+  if (!use_lds_) d_scratch_.alloc(L * work_stride_);
+  const int nh = nmax_ * g_.H;
+  block_ = nh <= 256 ? 64 : (nh <= 2048 ? 128 : 256);
+  block_ = env_int("RBL_CFR_BLOCK", block_);
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+Engine::~Engine() {
+  (void)hipSetDevice(device_);
+  if (stream_) (void)hipStreamSynchronize(stream_);
+  for (auto e : ev_pool_) (void)hipEventDestroy(e);
+  if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::check_lane(int lane) const {
+  if (lane < 0 || lane >= B_) throw std::runtime_error("engine: lane out of range");
+}
+
+// ---------------------------------------------------------------------------------------------- value net
+void Engine::set_net_zero() {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  net_mode_ = NetMode::kZero;
+  RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
+  values_zeroed_ = true;
+}
+
+void Engine::set_net_synthetic() {
+  net_mode_ = NetMode::kSynthetic;
+  values_zeroed_ = false;
+}
+
+void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
+  if (!fn) throw std::runtime_error("set_net_callback: null function");
+  net_mode_ = NetMode::kCallback;
+  cb_fn_ = fn;
+  cb_user_ = user;
+  cb_host_ = host_buffers;
+  values_zeroed_ = false;
+}
+
+void Engine::set_net_mlp(const rbl_mlp_weights& w) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (w.n_in != g_.query_size())
+    throw std::runtime_error("set_net_mlp: net input size " + std::to_string(w.n_in) + " != query size " +
+                             std::to_string(g_.query_size()));
+  if (w.n_out != g_.H)
+    throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
+                             std::to_string(g_.H));
+  MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
+                          w.w_out, w.b_out);
+  // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches on the engine stream
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  d_mlp_blob_.upload(pk.blob, stream_);
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  mlp_ = MlpDev{};
+  mlp_.n_layers = w.n_layers;
+  mlp_.n_in = w.n_in;
+  mlp_.n_hidden = w.n_hidden;
+  mlp_.n_out = w.n_out;
+  mlp_.use_ln = w.use_layer_norm;
+  mlp_.k0_steps = pk.k0_steps;
+  mlp_.out_tiles = pk.out_tiles;
+  mlp_.ln_eps = w.ln_eps > 0 ? w.ln_eps : 1e-5f;
+  const float* base = d_mlp_blob_.p;
+  mlp_.w0 = base + pk.off_w0;
+  mlp_.wh = base + pk.off_wh;
+  mlp_.wo = base + pk.off_wo;
+  mlp_.bias = base + pk.off_bias;
+  mlp_.ln_w = base + pk.off_lnw;
+  mlp_.ln_b = base + pk.off_lnb;
+  mlp_.b_out = base + pk.off_bout;
+  net_mode_ = NetMode::kMlp;
+  values_zeroed_ = false;
+}
+
+void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev) {
+  if (rows <= 0) return;
+  const int Q = g_.query_size(), H = g_.H;
+  switch (net_mode_) {
+    case NetMode::kZero:
+      RBL_HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)rows * H * sizeof(float), stream_));
+      break;
+    case NetMode::kSynthetic:
+      launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, stream_);
+      break;
+    case NetMode::kMlp:
+      launch_mlp_forward(mlp_, q_dev, rows, out_dev, stream_);
+      break;
+    case NetMode::kCallback:
+      if (cb_host_) {
+        h_q_.resize((size_t)rows * Q);
+        h_v_.assign((size_t)rows * H, 0.f);
+        RBL_HIP_CHECK(hipMemcpyAsync(h_q_.data(), q_dev, h_q_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+        cb_fn_(cb_user_, h_q_.data(), rows, Q, h_v_.data(), H, nullptr);
+        RBL_HIP_CHECK(hipMemcpyAsync(out_dev, h_v_.data(), h_v_.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+      } else {
+        cb_fn_(cb_user_, q_dev, rows, Q, out_dev, H, (void*)stream_);
+      }
+      break;
+  }
+  RBL_HIP_CHECK(hipGetLastError());
+}
+
+void Engine::net_forward_host(const float* q, int64_t rows, float* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (rows <= 0) return;
+  const size_t nq = (size_t)rows * g_.query_size(), no = (size_t)rows * g_.H;
+  if (d_tmp_q_.n < nq) d_tmp_q_.alloc(nq);
+  if (d_tmp_o_.n < no) d_tmp_o_.alloc(no);
+  RBL_HIP_CHECK(hipMemcpyAsync(d_tmp_q_.p, q, nq * sizeof(float), hipMemcpyHostToDevice, stream_));
+  net_forward_dev(d_tmp_q_.p, rows, d_tmp_o_.p);
+  RBL_HIP_CHECK(hipMemcpyAsync(out, d_tmp_o_.p, no * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// ---------------------------------------------------------------------------------------------- timing
+void Engine::timing(bool enable) { timing_ = enable; }
+
+void Engine::time_begin(int kind) {
+  if (!timing_) return;
+  while (ev_pool_.size() < ev_used_ + 2) {
+    hipEvent_t e;
+    RBL_HIP_CHECK(hipEventCreate(&e));
+    ev_pool_.push_back(e);
+  }
+  RBL_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_], stream_));
+  pending_.push_back(Pending{kind, ev_used_, ev_used_ + 1});
+  ev_used_ += 2;
+}
+
+void Engine::time_end(int) {
+  if (!timing_) return;
+  RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], stream_));
+}
+
+void Engine::stats(rbl_kernel_stats* out, bool reset) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  for (const auto& p : pending_) {
+    float ms = 0;
+    RBL_HIP_CHECK(hipEventElapsedTime(&ms, ev_pool_[p.e0], ev_pool_[p.e1]));
+    (p.kind == 0 ? stats_.cfr_ms : stats_.net_ms) += ms;
+  }
+  pending_.clear();
+  ev_used_ = 0;
+  if (out) *out = stats_;
+  if (reset) stats_ = rbl_kernel_stats{};
+}
+
+// ---------------------------------------------------------------------------------------------- solver batch
+void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_player, const double* beliefs,
+                   const int32_t* act_iteration) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (B < 1 || B > max_lanes_) throw std::runtime_error("reset: B must be in [1, max_lanes]");
+  const int H = g_.H, Q = g_.query_size();
+  h_shape_.resize(B);
+  h_player_.resize(B);
+  h_row_.resize(B);
+  h_bid_.resize(B);
+  h_act_.assign(B, -1);
+  h_beliefs_.assign(beliefs, beliefs + (size_t)B * 2 * H);
+  int64_t rows = 0;
+  step_bytes_[0] = step_bytes_[1] = 0;
+  for (int b = 0; b < B; ++b) {
+    const int rb = root_last_bid[b];
+    if (rb < -1 || rb >= g_.A - 1) throw std::runtime_error("reset: root_last_bid out of range (terminal or invalid state)");
+    if (root_player[b] != 0 && root_player[b] != 1) throw std::runtime_error("reset: root_player must be 0 or 1");
+    h_bid_[b] = rb;
+    h_shape_[b] = rb + 1;
+    h_player_[b] = root_player[b];
+    h_row_[b] = (int)rows;
+    const ShapeDev& s = tabs_.shapes[rb + 1];
+    rows += s.L;
+    if (act_iteration) {
+      if (act_iteration[b] < 0) throw std::runtime_error("reset: act_iteration must be >= 0");
+      h_act_[b] = act_iteration[b];
+    }
+    // algorithmic bytes of one step: read sigma over E, RMW regrets and sums + write sigma over E_t,
+    // write L queries, read L value rows
+    int e_par[2] = {0, 0};
+    for (int n = 1; n < s.N; ++n) ++e_par[tabs_.depth[s.node_off + tabs_.parent[s.node_off + n]] & 1];
+    for (int t = 0; t < 2; ++t) {
+      const int et = e_par[(root_player[b] == t) ? 0 : 1];
+      step_bytes_[t] += 8.0 * H * ((s.N - 1) + 5.0 * et) + 4.0 * s.L * (Q + H);
+    }
+  }
+  has_act_ = act_iteration != nullptr;
+  B_ = B;
+  rows_ = rows;
+  iter_ = 0;
+  num_steps_[0] = num_steps_[1] = 0;
+  d_lane_shape_.upload(h_shape_, stream_);
+  d_lane_player_.upload(h_player_, stream_);
+  d_lane_row_.upload(h_row_, stream_);
+  d_lane_act_.upload(h_act_, stream_);
+  d_beliefs_.upload(h_beliefs_, stream_);
+  launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
+  pending_trav_ = 0;
+}
+
+void Engine::launch(int mode, int trav, int next_trav, int steps_after, double alpha, double pos, double neg,
+                    double strat) {
+  CfrArgs a{};
+  a.shapes = d_shapes_.p;
+  a.parent = d_parent_.p;
+  a.act = d_act_.p;
+  a.cb = d_cb_.p;
+  a.ce = d_ce_.p;
+  a.depth = d_depth_.p;
+  a.leaves = d_leaves_.p;
+  a.terms = d_terms_.p;
+  a.matches = d_matches_.p;
+  a.H = g_.H;
+  a.A = g_.A;
+  a.Q = g_.query_size();
+  a.faces = g_.faces;
+  a.dice = g_.dice;
+  a.Emax = emax_;
+  a.Nmax = nmax_;
+  a.lane_shape = d_lane_shape_.p;
+  a.lane_root_player = d_lane_player_.p;
+  a.lane_row_off = d_lane_row_.p;
+  a.lane_act_iter = has_act_ ? d_lane_act_.p : nullptr;
+  a.beliefs = d_beliefs_.p;
+  a.sigma = d_sigma_.p;
+  a.regrets = d_regrets_.p;
+  a.sums = d_sums_.p;
+  a.snapshot = d_snapshot_.p;
+  a.root_mean = d_root_mean_.p;
+  a.queries = d_queries_.p;
+  a.values = d_values_.p;
+  a.scratch = d_scratch_.p;
+  a.work_stride = work_stride_;
+  a.use_lds = use_lds_ ? 1 : 0;
+  a.mode = mode;
+  a.trav = trav;
+  a.next_trav = next_trav;
+  a.steps_after = steps_after;
+  a.alpha = alpha;
+  a.pos = pos;
+  a.neg = neg;
+  a.strat = strat;
+  time_begin(0);
+  launch_cfr(a, B_, block_, lds_bytes_, stream_);
+  time_end(0);
+  RBL_HIP_CHECK(hipGetLastError());
+  if (mode == kModeStep) {
+    ++stats_.cfr_launches;
+    stats_.cfr_bytes += step_bytes_[trav];
+    stats_.lane_steps += B_;
+  }
+}
+
+void Engine::run_net() {
+  if (rows_ == 0) return;
+  if (net_mode_ == NetMode::kZero) {
+    if (!values_zeroed_) {
+      RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
+      values_zeroed_ = true;
+    }
+    return;
+  }
+  const bool timed = net_mode_ == NetMode::kMlp;
+  if (timed) time_begin(1);
+  net_forward_dev(d_queries_.p, rows_, d_values_.p);
+  if (timed) {
+    time_end(1);
+    ++stats_.net_launches;
+    stats_.net_rows += rows_;
+    stats_.net_flops += 2.0 * (double)rows_ *
+                        ((double)mlp_.n_in * mlp_.n_hidden + (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
+                         (double)mlp_.n_hidden * mlp_.n_out);
+  }
+}
+
+void Engine::step(int traverser) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (B_ == 0) throw std::runtime_error("step: no lanes (call reset first)");
+  if (traverser != 0 && traverser != 1) throw std::runtime_error("step: traverser must be 0 or 1");
+  if (pending_trav_ != traverser) {  // queries on the device were encoded for the other traverser: re-encode
+    launch(kModeQueries, 0, traverser, 0, 0, 1, 1, 1);
+    pending_trav_ = traverser;
+  }
+  run_net();
+  const int k = num_steps_[traverser];
+  // running mean step (subgame_solving.cc:580-590) and discounts (:592-617); "+1": the uniform strategy counts
+  const double alpha = p_.linear_update ? 2. / (k + 2) : 1. / (k + 1);
+  double pos = 1, neg = 1, strat = 1;
+  {
+    const double s = k + 1;
+    if (p_.linear_update) {
+      pos = neg = strat = s / (s + 1);
+    } else if (p_.dcfr) {
+      pos = p_.dcfr_alpha >= 5 ? 1 : std::pow(s, p_.dcfr_alpha) / (std::pow(s, p_.dcfr_alpha) + 1.);
+      neg = p_.dcfr_beta <= -5 ? 0 : std::pow(s, p_.dcfr_beta) / (std::pow(s, p_.dcfr_beta) + 1.);
+      strat = std::pow(s / (s + 1), p_.dcfr_gamma);
+    }
+  }
+  launch(kModeStep, traverser, 1 - traverser, iter_ + 1, alpha, pos, neg, strat);
+  ++num_steps_[traverser];
+  ++iter_;
+  pending_trav_ = 1 - traverser;
+}
+
+void Engine::multistep(int n) {
+  if (n < 0) n = p_.num_iters;
+  for (int i = 0; i < n; ++i) step(iter_ % 2);  // traverser = iteration parity (subgame_solving.cc:666-670)
+}
+
+void Engine::sync() {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+int Engine::tree_size(int lane) const {
+  check_lane(lane);
+  return tabs_.shapes[h_shape_[lane]].N;
+}
+
+void Engine::read_lane(const double* dev_base, int lane, std::vector<double>* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  const size_t eh = (size_t)emax_ * g_.H;
+  out->resize(eh);
+  RBL_HIP_CHECK(hipMemcpyAsync(out->data(), dev_base + (size_t)lane * eh, eh * sizeof(double), hipMemcpyDeviceToHost,
+                               stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// edge-indexed [E][H] -> the reference's dense TreeStrategy [N][H][A] (zeros outside the legal range)
+void Engine::expand_dense(int lane, const std::vector<double>& edge, double* out) const {
+  const ShapeDev& s = tabs_.shapes[h_shape_[lane]];
+  const int H = g_.H, A = g_.A;
+  std::fill(out, out + (size_t)s.N * H * A, 0.0);
+  for (int n = 1; n < s.N; ++n) {
+    const int p = tabs_.parent[s.node_off + n], a = tabs_.act[s.node_off + n];
+    for (int h = 0; h < H; ++h) out[((size_t)p * H + h) * A + a] = edge[(size_t)(n - 1) * H + h];
+  }
+}
+
+void Engine::get(int lane, int which, double* out) {
+  check_lane(lane);
+  std::vector<double> edge;
+  const ShapeDev& s = tabs_.shapes[h_shape_[lane]];
+  const int H = g_.H, A = g_.A;
+  switch (which) {
+    case RBL_GET_LAST:
+      read_lane(d_sigma_.p, lane, &edge);
+      expand_dense(lane, edge, out);
+      return;
+    case RBL_GET_REGRETS:
+      read_lane(d_regrets_.p, lane, &edge);
+      expand_dense(lane, edge, out);
+      return;
+    case RBL_GET_SUM:
+      read_lane(d_sums_.p, lane, &edge);
+      expand_dense(lane, edge, out);
+      return;
+    case RBL_GET_AVERAGE: {
+      // average_strategies = normalised sum_strategies on every node whose mover has stepped (subgame_solving.cc:658-660);
+      // rows never touched keep the uniform initialisation (:518-519)
+      read_lane(d_sums_.p, lane, &edge);
+      expand_dense(lane, edge, out);
+      for (int n = 0; n < s.N; ++n) {
+        const int c0 = tabs_.cb[s.node_off + n], c1 = tabs_.ce[s.node_off + n];
+        if (c0 == c1) continue;
+        const int mover = h_player_[lane] ^ (tabs_.depth[s.node_off + n] & 1);
+        for (int h = 0; h < H; ++h) {
+          double* row = out + ((size_t)n * H + h) * A;
+          if (num_steps_[mover] == 0) {
+            for (int c = c0; c < c1; ++c) row[tabs_.act[s.node_off + c]] = 1. / (c1 - c0);
+          } else {
+            double sum = 0;
+            for (int a = 0; a < A; ++a) sum += row[a];
+            for (int a = 0; a < A; ++a) row[a] = row[a] / sum;
+          }
+        }
+      }
+      return;
+    }
+    default:
+      throw std::runtime_error("get: bad selector");
+  }
+}
+
+void Engine::get_snapshot(int lane, double* out) {
+  check_lane(lane);
+  if (!has_act_) throw std::runtime_error("get_snapshot: reset was called without act_iteration");
+  if (iter_ < h_act_[lane]) throw std::runtime_error("get_snapshot: lane has not reached its act_iteration yet");
+  std::vector<double> edge;
+  read_lane(d_snapshot_.p, lane, &edge);
+  expand_dense(lane, edge, out);
+}
+
+void Engine::hand_values(int lane, int player, double* out) {
+  check_lane(lane);
+  if (player != 0 && player != 1) throw std::runtime_error("hand_values: player must be 0 or 1");
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipMemcpyAsync(out, d_root_mean_.p + ((size_t)lane * 2 + player) * g_.H, g_.H * sizeof(double),
+                               hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::write_root_query(int traverser, int last_bid, int player, const double* b0, const double* b1,
+                              float* q) const {  // write_query_to, subgame_solving.cc:104-123
+  int w = 0;
+  q[w++] = (float)player;
+  q[w++] = (float)traverser;
+  for (int a = 0; a < g_.A; ++a) q[w++] = (a == last_bid) ? 1.0f : 0.0f;
+  normalize_safe(b0, g_.H, kEps, q + w);
+  w += g_.H;
+  normalize_safe(b1, g_.H, kEps, q + w);
+}
+
+void Engine::examples(int lane, float* queries, float* values) {  // update_value_network, subgame_solving.cc:672-676
+  check_lane(lane);
+  const int H = g_.H, Q = g_.query_size();
+  std::vector<double> rm(2 * H);
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipMemcpyAsync(rm.data(), d_root_mean_.p + (size_t)lane * 2 * H, 2 * H * sizeof(double),
+                               hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  const double* b = h_beliefs_.data() + (size_t)lane * 2 * H;
+  for (int t = 0; t < 2; ++t) {
+    write_root_query(t, h_bid_[lane], h_player_[lane], b, b + H, queries + (size_t)t * Q);
+    for (int h = 0; h < H; ++h) values[t * H + h] = (float)rm[t * H + h];  // double -> float (:224)
+  }
+}
+
+void Engine::get_queries(float* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (rows_ > 0)
+    RBL_HIP_CHECK(hipMemcpyAsync(out, d_queries_.p, (size_t)rows_ * g_.query_size() * sizeof(float),
+                                 hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  const size_t eh = (size_t)emax_ * g_.H;
+  snap->resize((size_t)B_ * eh);
+  root_mean->resize((size_t)B_ * 2 * g_.H);
+  RBL_HIP_CHECK(hipMemcpyAsync(snap->data(), d_snapshot_.p, snap->size() * sizeof(double), hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipMemcpyAsync(root_mean->data(), d_root_mean_.p, root_mean->size() * sizeof(double),
+                               hipMemcpyDeviceToHost, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// =================================================================================================== SelfPlay
+SelfPlay::SelfPlay(Engine* e, int n_lanes, const int32_t* seeds, double random_action_prob, bool sample_leaf)
+    : e_(e), n_(n_lanes), rap_((float)random_action_prob), leaf_(sample_leaf) {
+  if (n_lanes < 1 || n_lanes > e->max_lanes()) throw std::runtime_error("selfplay: n_lanes must be in [1, max_lanes]");
+  const Rules& g = e->rules();
+  for (int i = 0; i < n_; ++i) gen_.emplace_back(seeds[i]);  // RlRunner: std::mt19937 gen_(seed)
+  bid_.assign(n_, g.liar);  // "terminal": the first advance() starts a fresh game on every lane
+  player_.assign(n_, 0);
+  act_.assign(n_, 0);
+  beliefs_.assign((size_t)n_ * 2 * g.H, 0.0);
+}
+
+void SelfPlay::state(int lane, int32_t* last_bid, int32_t* player) const {
+  if (lane < 0 || lane >= n_) throw std::runtime_error("selfplay: lane out of range");
+  *last_bid = bid_[lane];
+  *player = player_[lane];
+}
+
+// beliefs[h] *= sigma[node][h][action]; normalize_beliefs_inplace (recursive_solving.cc:41-44)
+void SelfPlay::bayes(double* b, const double* sigma, int, int child, int H) const {
+  for (int h = 0; h < H; ++h) b[h] *= sigma[(size_t)(child - 1) * H + h];
+  normalize_safe(b, H, kEps, b);
+}
+
+void SelfPlay::sample_to_leaf(int lane, const double* sigma) {  // recursive_solving.cc:192-246
+  const Rules& g = e_->rules();
+  const ShapeTables& tb = e_->tables();
+  const ShapeDev& s = tb.shapes[bid_[lane] + 1];
+  const int H = g.H, A = g.A;
+  std::mt19937& gen = gen_[lane];
+  double* bel = beliefs_.data() + (size_t)lane * 2 * H;
+  const int root_player = player_[lane];
+  std::vector<int> path;  // child node ids
+  {
+    int n = 0;
+    const int br_sampler = std::uniform_int_distribution<>(0, 1)(gen);
+    std::vector<double> sb(bel, bel + 2 * H);
+    std::vector<double> row(A);
+    while (tb.cb[s.node_off + n] != tb.ce[s.node_off + n]) {
+      const float eps = std::uniform_real_distribution<float>(0, 1)(gen);
+      const int mover = root_player ^ (tb.depth[s.node_off + n] & 1);
+      const int c0 = tb.cb[s.node_off + n], c1 = tb.ce[s.node_off + n];
+      const int lo = tb.act[s.node_off + c0];
+      int action;
+      if (mover == br_sampler && eps < rap_) {
+        std::uniform_int_distribution<> dis(lo, lo + (c1 - c0) - 1);
+        action = dis(gen);
+      } else {
+        std::discrete_distribution<> hd(sb.begin() + mover * H, sb.begin() + (mover + 1) * H);
+        const int hand = hd(gen);
+        std::fill(row.begin(), row.end(), 0.0);
+        for (int c = c0; c < c1; ++c) row[tb.act[s.node_off + c]] = sigma[(size_t)(c - 1) * H + hand];
+        std::discrete_distribution<> ad(row.begin(), row.end());
+        action = ad(gen);
+      }
+      const int child = c0 + action - lo;
+      bayes(sb.data() + mover * H, sigma, 0, child, H);
+      path.push_back(child);
+      n = child;
+    }
+  }
+  for (int child : path) {  // second pass on the lane's real beliefs (:235-245)
+    bayes(bel + player_[lane] * H, sigma, 0, child, H);
+    bid_[lane] = tb.act[s.node_off + child];
+    player_[lane] = 1 - player_[lane];
+  }
+}
+
+void SelfPlay::sample_single(int lane, const double* sigma) {  // recursive_solving.cc:248-275
+  const Rules& g = e_->rules();
+  const ShapeTables& tb = e_->tables();
+  const ShapeDev& s = tb.shapes[bid_[lane] + 1];
+  const int H = g.H, A = g.A;
+  std::mt19937& gen = gen_[lane];
+  double* bel = beliefs_.data() + (size_t)lane * 2 * H;
+  const int br_sampler = std::uniform_int_distribution<>(0, 1)(gen);
+  const float eps = std::uniform_real_distribution<float>(0, 1)(gen);
+  int lo, hi;
+  g.bid_range(bid_[lane], &lo, &hi);
+  const int pl = player_[lane];
+  int action;
+  if (pl == br_sampler && eps < rap_) {
+    std::uniform_int_distribution<> dis(lo, hi - 1);
+    action = dis(gen);
+  } else {
+    std::discrete_distribution<> hd(bel + pl * H, bel + (pl + 1) * H);
+    const int hand = hd(gen);
+    std::vector<double> row(A, 0.0);
+    const int c0 = tb.cb[s.node_off], c1 = tb.ce[s.node_off];
+    for (int c = c0; c < c1; ++c) row[tb.act[s.node_off + c]] = sigma[(size_t)(c - 1) * H + hand];
+    std::discrete_distribution<> ad(row.begin(), row.end());
+    action = ad(gen);
+  }
+  const int c0 = tb.cb[s.node_off];
+  if (c0 == tb.ce[s.node_off]) throw std::runtime_error("selfplay: max_depth=0 subgame has no actions to sample");
+  bayes(bel + pl * H, sigma, 0, c0 + action - lo, H);
+  bid_[lane] = action;  // Game::act, liars_dice.h:121-129
+  player_[lane] = 1 - pl;
+}
+
+int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
+  const Rules& g = e_->rules();
+  const int H = g.H, Q = g.query_size();
+  const int num_iters = e_->params().num_iters;
+  // RlRunner::step (recursive_solving.cc:160-182), one subgame of it per lane
+  for (int i = 0; i < n_; ++i) {
+    if (bid_[i] == g.liar) {  // previous game over: state_ = root, beliefs_ uniform (:161-163)
+      bid_[i] = -1;
+      player_[i] = 0;
+      double* b = beliefs_.data() + (size_t)i * 2 * H;
+      for (int k = 0; k < 2 * H; ++k) b[k] = 1.0 / H;
+    }
+    act_[i] = std::uniform_int_distribution<>(0, num_iters)(gen_[i]);  // inclusive (:168-169)
+  }
+  std::vector<int32_t> root_bid(bid_), root_player(player_);
+  std::vector<double> root_beliefs(beliefs_);
+  e_->reset(n_, bid_.data(), player_.data(), beliefs_.data(), act_.data());
+  e_->multistep(num_iters);
+  e_->read_snapshots(&snap_, &rmean_);
+  const size_t eh = (size_t)e_->emax() * H;
+  ex_q_.resize((size_t)2 * n_ * Q);
+  ex_v_.resize((size_t)2 * n_ * H);
+  ex_lane_.resize((size_t)2 * n_);
+  for (int i = 0; i < n_; ++i) {
+    const double* sigma = snap_.data() + (size_t)i * eh;
+    if (leaf_)
+      sample_to_leaf(i, sigma);
+    else
+      sample_single(i, sigma);
+    if (bid_[i] == g.liar) ++games_;
+    const double* rb = root_beliefs.data() + (size_t)i * 2 * H;
+    for (int t = 0; t < 2; ++t) {  // update_value_network (subgame_solving.cc:672-676)
+      const size_t k = (size_t)2 * i + t;
+      e_->write_root_query(t, root_bid[i], root_player[i], rb, rb + H, ex_q_.data() + k * Q);
+      for (int h = 0; h < H; ++h) ex_v_[k * H + h] = (float)rmean_[((size_t)i * 2 + t) * H + h];
+      ex_lane_[k] = i;
+    }
+  }
+  if (sink) sink(user, (int64_t)2 * n_, ex_lane_.data(), ex_q_.data(), Q, ex_v_.data(), H);
+  return (int64_t)n_ * num_iters;
+}
+
+}  // namespace rbl
+
+// =================================================================================================== C ABI
+struct rbl_engine {
+  rbl::Engine impl;
+  rbl_engine(int device, int dice, int faces, const rbl_params& p, int max_lanes)
+      : impl(device, dice, faces, p, max_lanes) {}
+};
+struct rbl_selfplay {
+  rbl::SelfPlay impl;
+  rbl_selfplay(rbl::Engine* e, int n, const int32_t* seeds, double rap, bool leaf) : impl(e, n, seeds, rap, leaf) {}
+};
+
+namespace {
+thread_local std::string g_err;
+template <class F>
+int guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& ex) {
+    g_err = ex.what();
+    return 1;
+  } catch (...) {
+    g_err = "unknown error";
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* rbl_last_error(void) { return g_err.c_str(); }
+
+int rbl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* rbl_build_info(void) { return "librebel_hip gfx950 (HIP " __VERSION__ ")"; }
+
+int rbl_num_actions(int dice, int faces) { return 1 + 2 * dice * faces; }
+int rbl_num_hands(int dice, int faces) {
+  int h = 1;
+  for (int i = 0; i < dice; ++i) h *= faces;
+  return h;
+}
+int rbl_query_size(int dice, int faces) { return 2 + rbl_num_actions(dice, faces) + 2 * rbl_num_hands(dice, faces); }
+
+int rbl_unroll_tree(int dice, int faces, int root_last_bid, int root_player, int max_depth, int32_t* out, int cap_nodes) {
+  int n = -1;
+  guard([&] {
+    rbl::Rules g(dice, faces);
+    auto t = rbl::unroll_tree(g, root_last_bid, root_player, max_depth);
+    n = (int)t.size();
+    for (int i = 0; i < n && i < cap_nodes; ++i) {
+      out[i * 6 + 0] = t[i].last_bid;
+      out[i * 6 + 1] = t[i].player;
+      out[i * 6 + 2] = t[i].cb;
+      out[i * 6 + 3] = t[i].ce;
+      out[i * 6 + 4] = t[i].parent;
+      out[i * 6 + 5] = t[i].depth;
+    }
+  });
+  return n;
+}
+
+rbl_engine* rbl_engine_create(int device, int dice, int faces, const rbl_params* params, int max_lanes) {
+  rbl_engine* e = nullptr;
+  guard([&] {
+    if (!params) throw std::runtime_error("rbl_engine_create: params is null");
+    e = new rbl_engine(device, dice, faces, *params, max_lanes);
+  });
+  return e;
+}
+void rbl_engine_destroy(rbl_engine* e) { delete e; }
+void* rbl_engine_stream(rbl_engine* e) { return (void*)e->impl.stream(); }
+
+int rbl_engine_set_net_zero(rbl_engine* e) { return guard([&] { e->impl.set_net_zero(); }); }
+int rbl_engine_set_net_synthetic(rbl_engine* e) { return guard([&] { e->impl.set_net_synthetic(); }); }
+int rbl_engine_set_net_mlp(rbl_engine* e, const rbl_mlp_weights* w) {
+  return guard([&] {
+    if (!w) throw std::runtime_error("rbl_engine_set_net_mlp: weights is null");
+    e->impl.set_net_mlp(*w);
+  });
+}
+int rbl_engine_set_net_callback(rbl_engine* e, rbl_net_fn fn, void* user, int host_buffers) {
+  return guard([&] { e->impl.set_net_callback(fn, user, host_buffers != 0); });
+}
+int rbl_net_forward(rbl_engine* e, const float* queries, int64_t rows, float* out) {
+  return guard([&] { e->impl.net_forward_host(queries, rows, out); });
+}
+int rbl_net_forward_dev(rbl_engine* e, const float* queries_dev, int64_t rows, float* out_dev) {
+  return guard([&] { e->impl.net_forward_dev(queries_dev, rows, out_dev); });
+}
+
+int rbl_solver_reset(rbl_engine* e, int B, const int32_t* root_last_bid, const int32_t* root_player,
+                     const double* beliefs, const int32_t* act_iteration) {
+  return guard([&] { e->impl.reset(B, root_last_bid, root_player, beliefs, act_iteration); });
+}
+int rbl_solver_step(rbl_engine* e, int traverser) { return guard([&] { e->impl.step(traverser); }); }
+int rbl_solver_multistep(rbl_engine* e, int n) { return guard([&] { e->impl.multistep(n); }); }
+int rbl_solver_sync(rbl_engine* e) { return guard([&] { e->impl.sync(); }); }
+int rbl_solver_num_lanes(rbl_engine* e) { return e->impl.num_lanes(); }
+int rbl_solver_tree_size(rbl_engine* e, int lane) {
+  int n = -1;
+  guard([&] { n = e->impl.tree_size(lane); });
+  return n;
+}
+int64_t rbl_solver_total_rows(rbl_engine* e) { return e->impl.total_rows(); }
+int rbl_solver_get(rbl_engine* e, int lane, int which, double* out) {
+  return guard([&] { e->impl.get(lane, which, out); });
+}
+int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out) {
+  return guard([&] { e->impl.get_snapshot(lane, out); });
+}
+int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out) {
+  return guard([&] { e->impl.hand_values(lane, player, out); });
+}
+int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values) {
+  return guard([&] { e->impl.examples(lane, queries, values); });
+}
+int rbl_solver_get_queries(rbl_engine* e, float* out) { return guard([&] { e->impl.get_queries(out); }); }
+
+rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
+                                  int sample_leaf) {
+  rbl_selfplay* sp = nullptr;
+  guard([&] { sp = new rbl_selfplay(&e->impl, n_lanes, seeds, random_action_prob, sample_leaf != 0); });
+  return sp;
+}
+void rbl_selfplay_destroy(rbl_selfplay* sp) { delete sp; }
+int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user) {
+  int64_t n = -1;
+  guard([&] { n = sp->impl.advance(sink, user); });
+  return n;
+}
+int64_t rbl_selfplay_games_finished(rbl_selfplay* sp) { return sp->impl.games_finished(); }
+int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id) {
+  return guard([&] { sp->impl.state(lane, last_bid, player_id); });
+}
+
+int rbl_engine_timing(rbl_engine* e, int enable) { return guard([&] { e->impl.timing(enable != 0); }); }
+int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset) {
+  return guard([&] { e->impl.stats(out, reset != 0); });
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// rebel_amd/csrc/net_kernels.h -- launch interface of the fused value-net forward (net_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+namespace rbl {
+
+// Device-resident, MFMA-ready copy of a Net2 (cfvpy/models.py:64-94).  Built by pack_mlp() from torch-layout weights.
+struct MlpDev {
+  int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
+  int k0_steps = 0;   // layer-0 k-pairs, padded to a multiple of 4
+  int out_tiles = 0;  // ceil(n_out / 32)
+  float ln_eps = 1e-5f;
+  const float* w0 = nullptr;     // [NT][k0_steps/4][64][4]
+  const float* wh = nullptr;     // [n_layers-1][NT][NT][4][64][4]
+  const float* wo = nullptr;     // [out_tiles][NT][4][64][4]
+  const float* bias = nullptr;   // [n_layers][n_hidden]
+  const float* ln_w = nullptr;   // [n_layers][n_hidden]
+  const float* ln_b = nullptr;   // [n_layers][n_hidden]
+  const float* b_out = nullptr;  // [out_tiles*32]
+};
+
+// Host-side packing: returns one float blob plus the offsets of the members above (in floats).
+struct MlpPacked {
+  std::vector<float> blob;
+  size_t off_w0, off_wh, off_wo, off_bias, off_lnw, off_lnb, off_bout;
+  int k0_steps, out_tiles;
+};
+MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
+                   const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
+                   const float* b_out);
+
+bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
+
+// out[rows][n_out] = net(queries[rows][n_in]); fp32 MFMA (v_mfma_f32_32x32x2_f32), async on `stream`.
+void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
+
+}  // namespace rbl

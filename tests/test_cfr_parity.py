@@ -1,0 +1,213 @@
+"""GPU parity tests (P1): the HIP CFR path, called through the C ABI (rebel_amd.capi -> librebel_hip.so), against the
+CPU oracle (oracle/, pinned to the compiled reference) and the committed golden vectors generated from the reference.
+
+Bar: bit-exact (np.array_equal on fp64 arrays / sha256) -- regrets, sum_strategies, last and average strategies, root
+value means, queries and training examples -- for identical leaf values (zero net, synthetic net, teacher-forced
+callback net).  See DESIGN.md "Parity protocol".
+"""
+import numpy as np
+import pytest
+
+from tests import golden_util as G
+from tests.cases import SOLVER_CASES, case_beliefs
+
+pytestmark = pytest.mark.gpu
+
+CFR_CASES = sorted(n for n, c in SOLVER_CASES.items() if c["p"].get("use_cfr"))
+
+
+def _engine(c, max_lanes=1):
+    from rebel_amd import capi
+
+    e = capi.Engine(c["d"], c["f"], capi.make_params(**c["p"]), max_lanes=max_lanes)
+    if c["net"] == "synthetic":
+        e.set_net_synthetic()
+    else:
+        e.set_net_zero()  # "none" cases are full-depth trees: no pseudo-leaves, the net is never consulted
+    return e
+
+
+def _oracle_solver(port, c, beliefs):
+    from oracle import orc
+    from tests.cases import NET_CODE
+
+    return port.solver(c["d"], c["f"], orc.make_params(**c["p"]), c.get("lb", -1), c.get("pl", 0), beliefs,
+                       NET_CODE[c["net"]])
+
+
+@pytest.mark.parametrize("name", CFR_CASES)
+def test_solver_bit_exact_vs_oracle_and_golden(name, port):
+    from oracle import orc
+    from rebel_amd import capi
+
+    c = SOLVER_CASES[name]
+    e = _engine(c)
+    b = case_beliefs(c, e.H)
+    o = _oracle_solver(port, c, b)
+    e.reset([c.get("lb", -1)], [c.get("pl", 0)], b[None])
+    assert e.tree_size(0) == o.N
+    n_it = c["p"]["num_iters"]
+    pairs = [(capi.GET_AVERAGE, orc.GET_AVERAGE), (capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM),
+             (capi.GET_REGRETS, orc.GET_REGRETS)]
+    for w, ow in pairs:  # freshly built solver
+        assert np.array_equal(e.get(0, w), o.get(ow)), (name, "init", w)
+    checkpoints = {1, 2, 3, n_it // 2, n_it}
+    for it in range(n_it):
+        e.step(it % 2)
+        o.step(it % 2)
+        if it + 1 in checkpoints:
+            for w, ow in pairs:
+                assert np.array_equal(e.get(0, w), o.get(ow)), (name, it, w)
+            if it >= 1:
+                for pl in (0, 1):
+                    assert np.array_equal(e.hand_values(0, pl), o.hand_values(pl)), (name, it, pl)
+    arrays = {"average": e.get(0, capi.GET_AVERAGE), "last": e.get(0, capi.GET_LAST), "sum": e.get(0, capi.GET_SUM),
+              "regrets": e.get(0, capi.GET_REGRETS)}
+    G.check_solver_arrays(name, arrays, np.stack([e.hand_values(0, 0), e.hand_values(0, 1)]), exact=True)
+    if c["net"] != "none":
+        q, v = e.examples(0)
+        g = G.load("solver_cases.npz")
+        assert np.array_equal(q, g[f"{name}/example_queries"])
+        assert np.array_equal(v, g[f"{name}/example_values"])
+
+
+def test_multistep_matches_golden():
+    """The fused multistep path (no host round trips between iterations) ends on the golden state as well."""
+    from rebel_amd import capi
+
+    for name in ("1d6f_root_syn_1024", "2d3f_root_syn_1024", "1d4f_dcfr_syn_64"):
+        c = SOLVER_CASES[name]
+        e = _engine(c)
+        b = case_beliefs(c, e.H)
+        e.reset([c.get("lb", -1)], [c.get("pl", 0)], b[None])
+        e.multistep()
+        arrays = {"average": e.get(0, capi.GET_AVERAGE), "last": e.get(0, capi.GET_LAST),
+                  "sum": e.get(0, capi.GET_SUM), "regrets": e.get(0, capi.GET_REGRETS)}
+        G.check_solver_arrays(name, arrays, np.stack([e.hand_values(0, 0), e.hand_values(0, 1)]), exact=True)
+
+
+@pytest.mark.parametrize("d,f,iters", [(1, 6, 96), (2, 3, 48), (1, 4, 64)])
+def test_batched_heterogeneous_lanes_bit_exact(d, f, iters, port):
+    """Many lanes at different roots / movers / beliefs in ONE launch sequence: every lane equals its own oracle run."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+    A, H = port.num_actions(d, f), port.num_hands(d, f)
+    rng = np.random.default_rng(1234)
+    roots = list(range(-1, A - 1)) * 2 + [-1] * 5
+    B = len(roots)
+    players = rng.integers(0, 2, B)
+    beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
+    beliefs[3] = 1.0 / H
+    acts = rng.integers(0, iters + 1, B)
+    acts[0], acts[1] = 0, iters
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=B)
+    e.set_net_synthetic()
+    e.reset(roots, players, beliefs, acts)
+    e.multistep()
+    for b in range(B):
+        o = port.solver(d, f, orc.make_params(**kw), roots[b], int(players[b]), beliefs[b], orc.NET_SYNTHETIC)
+        snap = None
+        for it in range(iters):
+            if it == acts[b]:
+                snap = o.get(orc.GET_LAST)
+            o.step(it % 2)
+        if acts[b] == iters:
+            snap = o.get(orc.GET_LAST)
+        assert e.tree_size(b) == o.N
+        for w, ow in [(capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM), (capi.GET_REGRETS, orc.GET_REGRETS),
+                      (capi.GET_AVERAGE, orc.GET_AVERAGE)]:
+            assert np.array_equal(e.get(b, w), o.get(ow)), (b, roots[b], w)
+        assert np.array_equal(e.get_snapshot(b), snap), (b, "snapshot at act_iteration", acts[b])
+        for pl in (0, 1):
+            assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
+        o.update_value_network()
+        q, v = e.examples(b)
+        assert np.array_equal(q, np.stack([x for x, _ in o.examples]))
+        assert np.array_equal(v, np.stack([x for _, x in o.examples]))
+
+
+def test_callback_net_teacher_forcing(port):
+    """Leaf values supplied by the SAME host function on both sides: identical query streams, identical end state."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    d, f = 1, 6
+    A, H = port.num_actions(d, f), port.num_hands(d, f)
+    rng = np.random.default_rng(0)
+    W = rng.standard_normal((2 + A + 2 * H, H)).astype(np.float32) * 0.3
+    seen = {"gpu": [], "port": []}
+
+    def make(tag):
+        def fn(q):
+            seen[tag].append(q.copy())
+            return np.tanh(q @ W).astype(np.float32)
+        return fn
+
+    kw = dict(num_iters=200, max_depth=2, linear_update=True, use_cfr=True)
+    e = capi.Engine(d, f, capi.make_params(**kw))
+    e.set_net_callback(make("gpu"))
+    e.reset([-1], [0], np.full((1, 2, H), 1.0 / H))
+    e.multistep()
+    o = port.solver(d, f, orc.make_params(**kw), net=orc.NET_CALLBACK, net_fn=make("port"))
+    o.multistep()
+    assert len(seen["gpu"]) == len(seen["port"]) == 200
+    for x, y in zip(seen["gpu"], seen["port"]):
+        assert np.array_equal(x, y)
+    for w, ow in [(capi.GET_AVERAGE, orc.GET_AVERAGE), (capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM),
+                  (capi.GET_REGRETS, orc.GET_REGRETS)]:
+        assert np.array_equal(e.get(0, w), o.get(ow))
+
+
+def test_irregular_traverser_order(port):
+    """ISubgameSolver::step(traverser) with a non-alternating order (the engine re-encodes the pending queries)."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=10, max_depth=2, linear_update=False, use_cfr=True)
+    e = capi.Engine(1, 5, capi.make_params(**kw))
+    e.set_net_synthetic()
+    H = e.H
+    b = np.random.default_rng(5).dirichlet(np.ones(H), size=2)
+    e.reset([2], [1], b[None])
+    o = port.solver(1, 5, orc.make_params(**kw), 2, 1, b, orc.NET_SYNTHETIC)
+    for t in (0, 0, 1, 0, 1, 1, 1, 0):
+        e.step(t)
+        o.step(t)
+        assert np.array_equal(e.get(0, capi.GET_REGRETS), o.get(orc.GET_REGRETS))
+        assert np.array_equal(e.get(0, capi.GET_AVERAGE), o.get(orc.GET_AVERAGE))
+
+
+def test_queries_bit_exact_first_iteration(port):
+    """The [rows, Q] fp32 query matrix the net sees equals the oracle's, row for row (row order = BFS leaf order)."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=4, max_depth=2, linear_update=True, use_cfr=True)
+    seen = []
+
+    def fn(q):
+        seen.append(q.copy())
+        return np.zeros((q.shape[0], 9), np.float32)
+
+    b = np.random.default_rng(9).dirichlet(np.ones(9), size=2)
+    o = port.solver(2, 3, orc.make_params(**kw), 1, 1, b, orc.NET_CALLBACK, net_fn=fn)
+    o.step(0)
+    e = capi.Engine(2, 3, capi.make_params(**kw))
+    e.reset([1], [1], b[None])
+    assert np.array_equal(e.queries(), seen[0])
+
+
+def test_error_paths():
+    from rebel_amd import capi
+
+    with pytest.raises(capi.RebelError):  # FP solver is not on the GPU path
+        capi.Engine(1, 4, capi.make_params(num_iters=4, use_cfr=False))
+    e = capi.Engine(1, 4, capi.make_params(num_iters=4, use_cfr=True), max_lanes=2)
+    with pytest.raises(capi.RebelError):  # terminal root state
+        e.reset([e.A - 1], [0], np.full((1, 2, e.H), 0.25))
+    with pytest.raises(capi.RebelError):  # more lanes than the engine was sized for
+        e.reset([-1] * 3, [0] * 3, np.full((3, 2, e.H), 0.25))
+    with pytest.raises(capi.RebelError):
+        e.step(0)  # nothing was reset successfully
