@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline benchmark: self-play data generation for ReBeL on Liar's Dice, MI355X engine.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): subgame CFR iterations/sec, whole job, 1 die x 6 faces @ 1024 iterations per subgame.
+A "step" is one pass of the hot path over one batch: EVERY lane plays one subgame of its self-play game end to end --
+build_solver, 1024 x [batched value-net forward on MFMA + CFR step kernel], sigma snapshot at the lane's act_iteration,
+host-side sampling of the next public state (libstdc++ <random>, the reference's draw order), 2 training examples per
+lane handed to the example sink.  One step = lanes x 1024 subgame-CFR-iterations.  Work is sharded across GPUs as
+independent lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
+
+The JSON line also carries
+  roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
+                measured live with HIP events on the engine stream (every 8th iteration of the timed region)
+  roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration
+  cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so, cpu_gen_threads = host cores) timed for a fixed
+                window on this box's host cores -- a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBPS = 8000.0        # same guide: HBM3E spec peak
+
+
+def cpu_baseline(dice, faces, iters, seconds):
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--dice", str(dice), "--faces", str(faces),
+           "--iters", str(iters), "--seconds", str(seconds)]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=seconds + 240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        out = json.loads(line)
+        if "error" in out:
+            raise RuntimeError(out["error"])
+        return {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "threads")}
+    except Exception as ex:  # the reference build is absent: fall back to timing the port oracle (zero net), 1 thread
+        from oracle import orc
+
+        port = orc.Oracle("port")
+        p = orc.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+        t0, games, subgames = time.time(), 0, 0.0
+        while time.time() - t0 < seconds:
+            subgames += len(port.rl_run(dice, faces, p, games, 1, net=orc.NET_SYNTHETIC)) / 2
+            games += 1
+        return {"value": subgames * iters / (time.time() - t0), "unit": "subgame-CFR-iterations/s", "cores": 1,
+                "kind": "port",
+                "sample": f"reference build unavailable ({ex}); port oracle, 1 thread, {games} games, elementwise "
+                          f"synthetic net instead of Net2 (so this OVERSTATES the CPU path)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("BENCH_LANES", 4096)))
+    ap.add_argument("--iters", type=int, default=int(os.environ.get("BENCH_ITERS", 1024)))
+    ap.add_argument("--dice", type=int, default=1)
+    ap.add_argument("--faces", type=int, default=6)
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("BENCH_CPU_SECONDS", 20)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+
+    import numpy as np
+    import torch  # first: librebel_hip.so then binds to the HIP runtime torch already loaded (same SONAME)
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: rebel_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from rebel_amd import capi
+    from rebel_amd.models import Net2, mlp_weights_from_state_dict
+    from rebel_amd.sharding import lane_seeds, reduce_job
+
+    torch.manual_seed(0)  # same random-init net on every rank (weights are read-only shared state)
+    net = Net2(num_faces=a.faces, num_dice=a.dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    params = capi.make_params(num_iters=a.iters, max_depth=2, linear_update=True, use_cfr=True)
+    eng = capi.Engine(a.dice, a.faces, params, max_lanes=a.lanes, device=local_rank)
+    eng.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
+    seeds = lane_seeds(rank, a.lanes)
+    sp = capi.SelfPlay(eng, seeds, random_action_prob=0.25, sample_leaf=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        sp.advance(collect=False)
+    eng.sync()
+    eng.stats(reset=True)
+    eng.timing(8)
+    n_examples, games0 = 0, sp.games_finished()
+    barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(a.steps):
+        n, lanes, q, v = sp.advance(collect=True)  # examples land in host arrays = the replay push hand-off
+        units += n
+        n_examples += len(lanes)
+    eng.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats(reset=True)
+    eng.timing(0)
+    games = sp.games_finished() - games0
+
+    dt_max, units_all, games_all = reduce_job(dist, world, dt, float(units), float(games))
+
+    if rank == 0:
+        net_t = st["net_ms"] / max(1, st["net_launches"]) * 1e-3
+        cfr_t = st["cfr_ms"] / max(1, st["cfr_launches"]) * 1e-3
+        net_tf = st["net_flops"] / max(1, st["net_launches"]) / net_t / 1e12 if net_t > 0 else 0.0
+        cfr_gb = st["cfr_bytes"] / max(1, st["cfr_launches"]) / cfr_t / 1e9 if cfr_t > 0 else 0.0
+        out = {
+            "metric": "subgame CFR iters/sec (whole job), 1dx6f @1024 iters; self-play games/sec in games_per_s",
+            "value": units_all / dt_max,
+            "unit": "subgame-CFR-iterations/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt_max / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 CFR state / f32 value net (fp32 MFMA)",
+            "data": "synthetic (self-play from the root state, random-init Net2 seed 0, lane seeds rank*lanes+i)",
+            "config": {"workload": f"{a.dice}dx{a.faces}f self-play data generation, subgame_iters={a.iters}, "
+                                   f"max_depth=2, linear CFR, sample_leaf, random_action_prob=0.25, {a.lanes} concurrent "
+                                   f"lanes per GPU, Net2(n_hidden=256,n_layers=2,layer_norm) batched forward on MFMA",
+                       "lanes_per_gpu": a.lanes, "subgame_iters": a.iters, "parallelism": f"independent lane sets x{world}"},
+            "games_per_s": games_all / dt_max,
+            "examples_per_s": n_examples * world / dt_max,
+            "roofline": {"kernel": "mlp_forward_kernel<8,1>", "bound": "mfma", "achieved": net_tf,
+                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
+                         "rows_per_launch": st["net_rows"] / max(1, st["net_launches"])},
+            "roofline_cfr": {"kernel": "cfr_step_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
+                             "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"]},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            del sp, eng
+            out["cpu_baseline"] = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
+            if out["cpu_baseline"].get("value"):
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

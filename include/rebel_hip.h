@@ -48,7 +48,8 @@ typedef struct {
 
 /* IValueNet::compute_values (net_interface.h:28) as a callback: fill out[rows][n_out] from queries[rows][qsize].
  * With host_buffers=1 the pointers are host memory (engine copies D2H/H2D around the call); with 0 they are device
- * pointers on the engine's device and the callee must enqueue its work on `stream` (a hipStream_t). */
+ * pointers on the engine's device: the engine stream is idle during the call, and the callee must either enqueue its
+ * work on `stream` (a hipStream_t) or have completed its writes to `out` before it returns. */
 typedef void (*rbl_net_fn)(void* user, const float* queries, int64_t rows, int64_t qsize, float* out, int64_t n_out,
                            void* stream);
 /* IValueNet::add_training_example (net_interface.h:31-32), batched: n examples, lane ids for bookkeeping. */
@@ -117,13 +118,14 @@ int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* p
 
 /* ---- timing of the two dominant kernels since the last reset (HIP events on the engine stream) ---- */
 typedef struct {
-  double cfr_ms, net_ms;     /* summed kernel time */
-  int64_t cfr_launches, net_launches;
-  int64_t net_rows;          /* rows pushed through the net */
-  int64_t lane_steps;        /* subgame-CFR-iterations */
-  double cfr_bytes, net_flops; /* algorithmic bytes / flops of those launches (DESIGN.md formulas, per-lane shapes) */
+  double cfr_ms, net_ms;              /* summed duration of the TIMED launches */
+  int64_t cfr_launches, net_launches; /* number of timed launches */
+  int64_t net_rows;                   /* rows pushed through the net by the timed launches */
+  int64_t lane_steps;                 /* subgame-CFR-iterations executed (all launches, timed or not) */
+  double cfr_bytes, net_flops;        /* algorithmic bytes / flops of the timed launches (per-lane shapes) */
 } rbl_kernel_stats;
-int rbl_engine_timing(rbl_engine* e, int enable); /* enable per-launch event timing (serialises; bench only) */
+/* stride = 0: off; n > 0: bracket the CFR and net launches of every n-th iteration with HIP events */
+int rbl_engine_timing(rbl_engine* e, int stride);
 int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset);
 
 #ifdef __cplusplus

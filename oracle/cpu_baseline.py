@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""CPU baseline = the UNMODIFIED reference data-generation path, timed on this host's cores.  TEST INFRASTRUCTURE ONLY
+(used by bench.py's `cpu_baseline` leg; never imported by rebel_amd/).
+
+Drives oracle/_ref/rela*.so -- the reference's own pybind11 module compiled from /root/reference/csrc/liars_dice by
+oracle/Makefile -- exactly the way cfvpy/selfplay.py:187-252 does for `cpu_gen_threads`: one TorchScript Net2 replica
++ one ModelLocker("cpu") per generator thread, T x create_cfr_thread(locker, replay, cfg, seed=i), Context.start(),
+and measures replay.num_add() over a fixed window (cfvpy/selfplay.py:285-293).  One subgame = 2 examples = num_iters
+subgame-CFR-iterations.
+
+Run as a subprocess:  python oracle/cpu_baseline.py --dice 1 --faces 6 --iters 1024 --threads 8 --seconds 20
+Prints one JSON line.
+"""
+import argparse
+import glob
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dice", type=int, default=1)
+    ap.add_argument("--faces", type=int, default=6)
+    ap.add_argument("--iters", type=int, default=1024)
+    ap.add_argument("--threads", type=int, default=0, help="generator threads (0 = os.cpu_count())")
+    ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--warmup", type=float, default=3.0)
+    a = ap.parse_args()
+    if not glob.glob(os.path.join(HERE, "_ref", "rela*.so")):
+        print(json.dumps({"error": "oracle/_ref/rela*.so not built (needs /root/reference: make -C oracle ref)"}))
+        return 2
+    import torch
+
+    torch.set_num_threads(1)  # one intra-op thread per generator thread (5x effect)
+    sys.path.insert(0, os.path.join(HERE, "_ref"))
+    sys.path.insert(0, ROOT)
+    import rela  # the reference's module
+    from rebel_amd.models import Net2  # same keys/init as the reference's class (checked in tests)
+
+    T = a.threads or os.cpu_count()
+    torch.manual_seed(0)
+    net = Net2(num_faces=a.faces, num_dice=a.dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    models, lockers = [], []
+    for _ in range(T):
+        m = torch.jit.script(net)
+        models.append(m)
+        lockers.append(rela.ModelLocker([m], "cpu"))
+    replay = rela.ValuePrioritizedReplay(capacity=2 ** 20, seed=10001, alpha=1.0, beta=0.4, prefetch=3,
+                                         use_priority=False, compressed_values=False)
+    cfg = rela.RecursiveSolvingParams()
+    cfg.num_dice, cfg.num_faces = a.dice, a.faces
+    cfg.random_action_prob, cfg.sample_leaf = 0.25, True
+    sp = cfg.subgame_params
+    sp.num_iters, sp.max_depth, sp.linear_update, sp.use_cfr = a.iters, 2, True, True
+    ctx = rela.Context()
+    for i in range(T):
+        ctx.push_env_thread(rela.create_cfr_thread(lockers[i], replay, cfg, i))
+    ctx.start()
+    time.sleep(a.warmup)
+    n0, t0 = replay.num_add(), time.time()
+    time.sleep(a.seconds)
+    n1, t1 = replay.num_add(), time.time()
+    subgames = (n1 - n0) / 2
+    out = {"value": subgames * a.iters / (t1 - t0), "unit": "subgame-CFR-iterations/s", "cores": os.cpu_count(),
+           "threads": T, "kind": "reference", "subgames_per_s": subgames / (t1 - t0),
+           "sample": f"{a.dice}dx{a.faces}f, {a.iters} iters/subgame, {T} reference gen threads x {a.seconds:.0f}s window, "
+                     f"Net2(256x2,LN) TorchScript on CPU, torch intra-op threads=1"}
+    print(json.dumps(out), flush=True)
+    os._exit(0)  # generator threads only honour terminate() between games; do not wait for them
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -274,8 +274,9 @@ class Engine:
         return out
 
     # ---- accounting
-    def timing(self, enable=True):
-        _check(self.L.rbl_engine_timing(self.h, int(enable)))
+    def timing(self, stride=1):
+        """0 = off; n = bracket the kernels of every n-th CFR iteration with HIP events (engine stream)."""
+        _check(self.L.rbl_engine_timing(self.h, int(stride)))
 
     def stats(self, reset=False):
         s = KernelStats()

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -86,7 +87,7 @@ class Engine {
   // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
   void read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean);
 
-  void timing(bool enable);
+  void timing(int stride);  // 0 = off, n = time the launches of every n-th CFR iteration with HIP events
   void stats(rbl_kernel_stats* out, bool reset);
 
   const Rules& rules() const { return g_; }
@@ -128,6 +129,7 @@ class Engine {
   bool has_act_ = false;
   int iter_ = 0, num_steps_[2] = {0, 0}, pending_trav_ = -1;
 
+  std::mutex net_mutex_;  // weight refresh (another thread) vs the net launch inside step()
   NetMode net_mode_ = NetMode::kZero;
   bool values_zeroed_ = false;
   MlpDev mlp_;
@@ -142,6 +144,8 @@ class Engine {
 
   // accounting
   bool timing_ = false;
+  int timing_stride_ = 0;
+  bool timed_now() const { return timing_ && (iter_ % timing_stride_ == 0); }
   std::vector<hipEvent_t> ev_pool_;
   struct Pending {
     int kind;

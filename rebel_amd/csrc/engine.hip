@@ -102,6 +102,7 @@ void Engine::check_lane(int lane) const {
 
 // ---------------------------------------------------------------------------------------------- value net
 void Engine::set_net_zero() {
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
   RBL_HIP_CHECK(hipSetDevice(device_));
   net_mode_ = NetMode::kZero;
   RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
@@ -109,11 +110,13 @@ void Engine::set_net_zero() {
 }
 
 void Engine::set_net_synthetic() {
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
   net_mode_ = NetMode::kSynthetic;
   values_zeroed_ = false;
 }
 
 void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (!fn) throw std::runtime_error("set_net_callback: null function");
   net_mode_ = NetMode::kCallback;
   cb_fn_ = fn;
@@ -123,6 +126,7 @@ void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
 }
 
 void Engine::set_net_mlp(const rbl_mlp_weights& w) {
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (w.n_in != g_.query_size())
     throw std::runtime_error("set_net_mlp: net input size " + std::to_string(w.n_in) + " != query size " +
@@ -179,7 +183,8 @@ void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev) {
         cb_fn_(cb_user_, h_q_.data(), rows, Q, h_v_.data(), H, nullptr);
         RBL_HIP_CHECK(hipMemcpyAsync(out_dev, h_v_.data(), h_v_.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
         RBL_HIP_CHECK(hipStreamSynchronize(stream_));
-      } else {
+      } else {  // device pointers: the engine stream is drained first; the callee returns with `out` complete
+        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
         cb_fn_(cb_user_, q_dev, rows, Q, out_dev, H, (void*)stream_);
       }
       break;
@@ -200,10 +205,13 @@ void Engine::net_forward_host(const float* q, int64_t rows, float* out) {
 }
 
 // ---------------------------------------------------------------------------------------------- timing
-void Engine::timing(bool enable) { timing_ = enable; }
+void Engine::timing(int stride) {
+  timing_stride_ = stride < 0 ? 0 : stride;
+  timing_ = timing_stride_ > 0;
+}
 
 void Engine::time_begin(int kind) {
-  if (!timing_) return;
+  if (!timed_now()) return;
   while (ev_pool_.size() < ev_used_ + 2) {
     hipEvent_t e;
     RBL_HIP_CHECK(hipEventCreate(&e));
@@ -215,7 +223,7 @@ void Engine::time_begin(int kind) {
 }
 
 void Engine::time_end(int) {
-  if (!timing_) return;
+  if (!timed_now()) return;
   RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], stream_));
 }
 
@@ -331,14 +339,17 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   time_end(0);
   RBL_HIP_CHECK(hipGetLastError());
   if (mode == kModeStep) {
-    ++stats_.cfr_launches;
-    stats_.cfr_bytes += step_bytes_[trav];
+    if (timed_now()) {
+      ++stats_.cfr_launches;
+      stats_.cfr_bytes += step_bytes_[trav];
+    }
     stats_.lane_steps += B_;
   }
 }
 
 void Engine::run_net() {
   if (rows_ == 0) return;
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (net_mode_ == NetMode::kZero) {
     if (!values_zeroed_) {
       RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
@@ -346,7 +357,7 @@ void Engine::run_net() {
     }
     return;
   }
-  const bool timed = net_mode_ == NetMode::kMlp;
+  const bool timed = net_mode_ == NetMode::kMlp && timed_now();
   if (timed) time_begin(1);
   net_forward_dev(d_queries_.p, rows_, d_values_.p);
   if (timed) {
@@ -815,7 +826,7 @@ int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* p
   return guard([&] { sp->impl.state(lane, last_bid, player_id); });
 }
 
-int rbl_engine_timing(rbl_engine* e, int enable) { return guard([&] { e->impl.timing(enable != 0); }); }
+int rbl_engine_timing(rbl_engine* e, int stride) { return guard([&] { e->impl.timing(stride); }); }
 int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset) {
   return guard([&] { e->impl.stats(out, reset != 0); });
 }

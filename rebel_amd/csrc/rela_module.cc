@@ -1,0 +1,845 @@
+// rebel_amd/csrc/rela_module.cc -- the drop-in for the reference's pybind11 module `cfvpy.rela`
+// (/root/reference/csrc/liars_dice/rela/pybind.cc:119-213), built on the C ABI of librebel_hip.so (include/rebel_hip.h).
+//
+// Same Python-visible names, argument meaning and error behaviour; a different machine underneath:
+//   * create_cfr_thread(model_locker, replay, cfg, seed) does not make a host thread that plays one game at a time
+//     (rela/data_loop.h:61-82).  It makes a *lane*.  Context.start() gathers the lanes that share a ModelLocker /
+//     replay / config into one GPU engine (rbl_engine) and one driver thread per engine, which advances all its lanes in
+//     lock-step: one CFR-kernel launch + one batched MFMA value-net forward per CFR iteration for ALL lanes.
+//   * ModelLocker does not keep a pool of TorchScript replicas to run tiny forwards on (rela/model_locker.h:54-103); it
+//     reads the Net2 weights out of the module's state_dict and hands them to the engine (rbl_engine_set_net_mlp).
+//     update_model() keeps the reference's Python-visible effect (load_state_dict on every replica) and re-uploads.
+//     A module that is not Net2-shaped still works: its TorchScript forward is called on the GPU for the whole batch.
+//   * ValuePrioritizedReplay keeps the reference's semantics (rela/prioritized_replay.h:224-504: 1.25x ring, blocking
+//     add, in-order publish, stratified priority sampling / uniform sampling, trim-on-sample, prefetch futures, file
+//     format of rela/types.cc:87-111) over flat float rings instead of a vector of tiny tensors, so the engine pushes
+//     all examples of an epoch with one block append.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <torch/extension.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include "../../include/rebel_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+[[noreturn]] void fail(const std::string& what) { throw std::runtime_error(what); }
+void check(int status, const char* where) {
+  if (status != 0) fail(std::string(where) + ": " + rbl_last_error());
+}
+
+// ------------------------------------------------------------------------------------------------ params
+struct SubgameSolvingParams {  // subgame_solving.h:43-58
+  int num_iters = 10;
+  int max_depth = 2;
+  bool linear_update = false;
+  bool use_cfr = false;
+  bool optimistic = false;
+  bool dcfr = false;
+  double dcfr_alpha = 0, dcfr_beta = 0, dcfr_gamma = 0;
+};
+struct RecursiveSolvingParams {  // recursive_solving.h:31-38
+  int num_dice = 0;
+  int num_faces = 0;
+  float random_action_prob = 1.0;
+  bool sample_leaf = false;
+  SubgameSolvingParams subgame_params;
+};
+rbl_params to_c(const SubgameSolvingParams& p) {
+  rbl_params c{};
+  c.num_iters = p.num_iters;
+  c.max_depth = p.max_depth;
+  c.linear_update = p.linear_update;
+  c.use_cfr = p.use_cfr;
+  c.optimistic = p.optimistic;
+  c.dcfr = p.dcfr;
+  c.dcfr_alpha = p.dcfr_alpha;
+  c.dcfr_beta = p.dcfr_beta;
+  c.dcfr_gamma = p.dcfr_gamma;
+  return c;
+}
+bool same(const RecursiveSolvingParams& a, const RecursiveSolvingParams& b) {
+  const auto &x = a.subgame_params, &y = b.subgame_params;
+  return a.num_dice == b.num_dice && a.num_faces == b.num_faces && a.random_action_prob == b.random_action_prob &&
+         a.sample_leaf == b.sample_leaf && x.num_iters == y.num_iters && x.max_depth == y.max_depth &&
+         x.linear_update == y.linear_update && x.use_cfr == y.use_cfr && x.optimistic == y.optimistic &&
+         x.dcfr == y.dcfr && x.dcfr_alpha == y.dcfr_alpha && x.dcfr_beta == y.dcfr_beta && x.dcfr_gamma == y.dcfr_gamma;
+}
+
+// ------------------------------------------------------------------------------------------------ ValueTransition
+struct ValueTransition {  // rela/types.h:39-64
+  torch::Tensor query, values;
+};
+
+// ------------------------------------------------------------------------------------------------ replay buffer
+class ValuePrioritizedReplay {
+ public:
+  ValuePrioritizedReplay(int capacity, int seed, float alpha, float beta, int prefetch, bool use_priority,
+                         bool compressed_values)
+      : alpha_(alpha), beta_(beta), prefetch_(prefetch), capacity_(capacity), use_priority_(use_priority),
+        compressed_values_(compressed_values), ring_((int)(1.25 * capacity)) {
+    if (ring_ < 1) fail("ValuePrioritizedReplay: capacity must be >= 1");
+    rng_.seed(seed);
+    weights_.assign(ring_, 0.f);
+    evicted_.assign(ring_, false);
+  }
+  ~ValuePrioritizedReplay() {
+    while (!futures_.empty()) {  // do not let prefetch threads outlive the rings
+      try {
+        futures_.front().get();
+      } catch (...) {
+      }
+      futures_.pop();
+    }
+  }
+
+  // ---- producer side: PrioritizedReplay::add (:247-261) -> ConcurrentQueue::blockAppend (:59-96)
+  // `stop` lets a generator that is being terminated leave a full buffer (the reference would block forever).
+  bool add_block(const float* q, int64_t Q, const float* v, int64_t V, int64_t n, const float* priority,
+                 const std::atomic<bool>* stop = nullptr) {
+    if (n <= 0) return true;
+    if (n > ring_) fail("replay: block larger than the buffer");
+    std::unique_lock<std::mutex> lk(m_);
+    ensure_layout(Q, V);
+    while (!(size_ + n <= ring_)) {
+      if (stop && stop->load()) return false;
+      cv_size_.wait_for(lk, std::chrono::milliseconds(50));
+    }
+    const int start = tail_;
+    const int end = (int)((tail_ + n) % ring_);
+    tail_ = end;
+    size_ += (int)n;
+    lk.unlock();
+    double sum = 0;
+    for (int64_t i = 0; i < n; ++i) {  // copy outside the lock, as the reference does
+      const int j = (int)((start + i) % ring_);
+      std::memcpy(&q_[(size_t)j * Q_], q + i * Q, sizeof(float) * Q);
+      std::memcpy(&v_[(size_t)j * V_], v + i * V, sizeof(float) * V);
+      const float w = use_priority_ ? std::pow(priority[i], alpha_) : priority[i];
+      weights_[j] = w;
+      sum += w;
+    }
+    lk.lock();
+    cv_tail_.wait(lk, [&] { return safe_tail_ == start; });  // publish in reservation order
+    safe_tail_ = end;
+    safe_size_ += (int)n;
+    sum_ += sum;
+    lk.unlock();
+    cv_tail_.notify_all();
+    num_add_ += (int)n;
+    return true;
+  }
+
+  int size() const {  // safeSize (:49-55)
+    std::lock_guard<std::mutex> lk(m_);
+    return safe_size_;
+  }
+  int num_add() const { return num_add_; }
+
+  // ---- consumer side: sample (:263-296)
+  std::tuple<ValueTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
+    if (!sampled_ids_.empty() && use_priority_)
+      fail("ValuePrioritizedReplay.sample: previous samples' priority has not been updated");
+    Sampled s;
+    if (prefetch_ == 0) {
+      s = sample_(batchsize, device);
+    } else {
+      if (futures_.empty()) {
+        s = sample_(batchsize, device);
+      } else {
+        s = futures_.front().get();
+        futures_.pop();
+      }
+      while ((int)futures_.size() < prefetch_)
+        futures_.push(std::async(std::launch::async, &ValuePrioritizedReplay::sample_, this, batchsize, device));
+    }
+    sampled_ids_ = std::move(std::get<2>(s));
+    return std::make_tuple(std::get<0>(s), std::get<1>(s));
+  }
+
+  void update_priority(const torch::Tensor& priority) {  // :298-313
+    if (priority.size(0) == 0) {
+      sampled_ids_.clear();
+      return;
+    }
+    if (priority.dim() != 1 || (int64_t)sampled_ids_.size() != priority.size(0))
+      fail("update_priority: expected a 1-d tensor with one entry per sampled element");
+    auto w = torch::pow(priority.to(torch::kCPU, torch::kFloat32), alpha_).contiguous();
+    const float* wp = w.data_ptr<float>();
+    {
+      std::lock_guard<std::mutex> ls(m_sampler_);
+      double diff = 0;
+      for (size_t i = 0; i < sampled_ids_.size(); ++i) {  // ConcurrentQueue::update (:160-172)
+        const int id = sampled_ids_[i];
+        if (evicted_[id]) continue;
+        diff += (double)wp[i] - weights_[id];
+        weights_[id] = wp[i];
+      }
+      std::lock_guard<std::mutex> lk(m_);
+      sum_ += diff;
+    }
+    sampled_ids_.clear();
+  }
+
+  void pop_until(int new_size) {  // :356-361
+    int size;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      size = size_;
+    }
+    if (size > new_size) block_pop(size - new_size);
+  }
+
+  // ---- persistence: one record = [int qn][int vn][qn x f32][vn x f32] (rela/types.cc:87-111)
+  void save(const std::string& path) {  // ConcurrentQueue::save (:123-130): slots [0, size), as the reference does
+    std::lock_guard<std::mutex> lk(m_);
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) fail("replay.save: cannot open " + path);
+    const int qn = (int)Q_, vn = (int)V_;
+    for (int i = 0; i < size_; ++i) {
+      std::fwrite(&qn, sizeof(int), 1, f);
+      std::fwrite(&vn, sizeof(int), 1, f);
+      std::fwrite(&q_[(size_t)i * Q_], sizeof(float), Q_, f);
+      std::fwrite(&v_[(size_t)i * V_], sizeof(float), V_, f);
+    }
+    std::fclose(f);
+  }
+
+  void load(const std::string& path, float priority, int max_size, int stride) {  // :319-333
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) fail("replay.load: cannot open " + path);
+    if (stride < 1) stride = 1;
+    std::vector<float> q, v;
+    for (int added = 0, i = 0;; ++i) {
+      if (max_size > 0 && added == max_size) break;
+      int qn, vn;
+      if (std::fread(&qn, sizeof(int), 1, f) != 1) break;
+      if (std::fread(&vn, sizeof(int), 1, f) != 1 || qn < 0 || vn < 0) break;
+      q.resize(qn);
+      v.resize(vn);
+      if (std::fread(q.data(), sizeof(float), qn, f) != (size_t)qn) break;
+      if (std::fread(v.data(), sizeof(float), vn, f) != (size_t)vn) break;
+      if (i % stride != 0) continue;
+      add_block(q.data(), qn, v.data(), vn, 1, &priority);
+      ++added;
+    }
+    std::fclose(f);
+  }
+
+  std::vector<torch::Tensor> extract() {  // :338-344 + ConcurrentQueue::extract (:132-158)
+    std::lock_guard<std::mutex> ls(m_sampler_);
+    int size, head;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      size = safe_size_;
+      head = head_;
+    }
+    auto q = torch::empty({size, (int64_t)Q_}, torch::kFloat32);
+    auto v = torch::empty({size, (int64_t)V_}, torch::kFloat32);
+    auto w = torch::empty({size}, torch::kFloat32);
+    for (int i = 0; i < size; ++i) {
+      const int j = (head + i) % ring_;
+      if (Q_) std::memcpy(q.data_ptr<float>() + (size_t)i * Q_, &q_[(size_t)j * Q_], sizeof(float) * Q_);
+      if (V_) std::memcpy(v.data_ptr<float>() + (size_t)i * V_, &v_[(size_t)j * V_], sizeof(float) * V_);
+      w.data_ptr<float>()[i] = weights_[j];
+    }
+    block_pop(size);
+    return {q, v, torch::pow(w, 1 / alpha_)};
+  }
+
+  void push(std::vector<torch::Tensor> data) {  // :347-353
+    if (data.size() != 3) fail("replay.push: expected [query, values, weights]");
+    auto q = data[0].to(torch::kCPU, torch::kFloat32).contiguous();
+    auto v = data[1].to(torch::kCPU, torch::kFloat32).contiguous();
+    auto w = data[2].to(torch::kCPU, torch::kFloat32).contiguous();
+    if (q.dim() != 2 || v.dim() != 2 || w.dim() != 1 || q.size(0) != v.size(0) || q.size(0) != w.size(0))
+      fail("replay.push: shapes must be [n,Q], [n,V], [n]");
+    const int64_t n = q.size(0), chunk = std::max<int64_t>(1, ring_ / 4);
+    for (int64_t s = 0; s < n; s += chunk) {
+      const int64_t k = std::min(chunk, n - s);
+      add_block(q.data_ptr<float>() + s * q.size(1), q.size(1), v.data_ptr<float>() + s * v.size(1), v.size(1), k,
+                w.data_ptr<float>() + s);
+    }
+  }
+
+ private:
+  using Sampled = std::tuple<ValueTransition, torch::Tensor, std::vector<int>>;
+
+  void ensure_layout(int64_t Q, int64_t V) {  // m_ held
+    if (Q_ < 0) {
+      Q_ = Q;
+      V_ = V;
+      q_.assign((size_t)ring_ * Q_, 0.f);
+      v_.assign((size_t)ring_ * V_, 0.f);
+    } else if (Q != Q_ || V != V_) {
+      fail("replay: transition width changed (" + std::to_string(Q) + "," + std::to_string(V) + ") vs (" +
+           std::to_string(Q_) + "," + std::to_string(V_) + ")");
+    }
+  }
+
+  void block_pop(int n) {  // ConcurrentQueue::blockPop (:102-121)
+    double diff = 0;
+    int head;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      head = head_;
+    }
+    for (int i = 0; i < n; ++i) {
+      diff -= weights_[head];
+      evicted_[head] = true;
+      head = (head + 1) % ring_;
+    }
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      sum_ += diff;
+      head_ = head;
+      safe_size_ -= n;
+      size_ -= n;
+    }
+    cv_size_.notify_all();
+  }
+
+  Sampled sample_(int batchsize, const std::string& device) {
+    std::unique_lock<std::mutex> ls(m_sampler_);
+    int size, head;
+    float sum;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      size = safe_size_;
+      sum = (float)sum_;
+      head = head_;
+    }
+    if (size <= 0) fail("ValuePrioritizedReplay.sample: buffer is empty");
+    ValueTransition batch;
+    batch.query = torch::empty({batchsize, (int64_t)Q_}, torch::kFloat32);
+    batch.values = torch::empty({batchsize, (int64_t)V_}, torch::kFloat32);
+    auto weights = torch::zeros({batchsize}, torch::kFloat32);
+    float* wacc = weights.data_ptr<float>();
+    std::vector<int> ids(batchsize);
+    auto take = [&](int i, int id) {
+      evicted_[id] = false;  // getElementAndMark (:177-181)
+      std::memcpy(batch.query.data_ptr<float>() + (size_t)i * Q_, &q_[(size_t)id * Q_], sizeof(float) * Q_);
+      std::memcpy(batch.values.data_ptr<float>() + (size_t)i * V_, &v_[(size_t)id * V_], sizeof(float) * V_);
+    };
+    if (use_priority_) {  // sample_with_priorities_ (:371-449): one draw per equal-mass segment
+      const float segment = sum / batchsize;
+      std::uniform_real_distribution<float> dist(0.0, segment);
+      double acc = 0;
+      int next = 0, id = 0;
+      float w = 0;
+      for (int i = 0; i < batchsize; ++i) {
+        float r = dist(rng_) + i * segment;
+        r = std::min(sum - (float)0.1, r);
+        while (next <= size) {
+          if ((acc > 0 && acc >= r) || next == size) {
+            if (next < 1) fail("replay: sampling invariant violated");
+            take(i, (head + next - 1) % ring_);
+            wacc[i] = w;
+            ids[i] = id;
+            break;
+          }
+          id = (head + next) % ring_;
+          w = weights_[id];
+          acc += w;
+          ++next;
+        }
+      }
+    } else {  // sample_no_priorities_ (:451-486)
+      std::uniform_int_distribution<> dist(0, size - 1);
+      for (int i = 0; i < batchsize; ++i) {
+        const int id = (head + dist(rng_)) % ring_;
+        wacc[i] = weights_[id];
+        ids[i] = id;
+        take(i, id);
+      }
+    }
+    int full;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      full = size_;
+    }
+    if (full > capacity_) block_pop(full - capacity_);  // pop storage if full (:429-433, :473-477)
+    ls.unlock();
+    if (use_priority_) {
+      weights = weights / sum;
+      weights = torch::pow(full * weights, -beta_);
+      weights /= weights.max();
+    }
+    if (device != "cpu") {
+      const torch::Device d(device);
+      weights = use_priority_ ? weights.to(d) : weights;
+      batch.query = batch.query.to(d);
+      batch.values = batch.values.to(d);
+    }
+    if (compressed_values_) batch.values = batch.values.to(torch::kFloat32) / 255;  // rela::dequantize
+    return std::make_tuple(batch, weights, ids);
+  }
+
+  const float alpha_, beta_;
+  const int prefetch_, capacity_;
+  const bool use_priority_, compressed_values_;
+  const int ring_;
+  mutable std::mutex m_;
+  std::condition_variable cv_size_, cv_tail_;
+  int head_ = 0, tail_ = 0, size_ = 0, safe_tail_ = 0, safe_size_ = 0;
+  double sum_ = 0;
+  int64_t Q_ = -1, V_ = -1;
+  std::vector<float> q_, v_, weights_;
+  std::vector<bool> evicted_;
+  std::atomic<int> num_add_{0};
+  std::mutex m_sampler_;
+  std::vector<int> sampled_ids_;
+  std::queue<std::future<Sampled>> futures_;
+  std::mt19937 rng_;
+};
+
+// ------------------------------------------------------------------------------------------------ model locker
+struct MlpHost {  // weights in torch.nn.Linear layout, owned
+  int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
+  std::vector<std::vector<float>> w, b, ln_w, ln_b;
+  std::vector<float> w_out, b_out;
+};
+
+std::vector<float> to_floats(const py::handle& t) {
+  auto x = py::cast<torch::Tensor>(t).detach().to(torch::kCPU, torch::kFloat32).contiguous();
+  return std::vector<float>(x.data_ptr<float>(), x.data_ptr<float>() + x.numel());
+}
+
+// Net2 state_dict contract (cfvpy/models.py:20-53,64-94): Linear at body.{4l}, LayerNorm at body.{4l+1}, `output`.
+bool parse_net2(const py::object& model, MlpHost* out, std::string* why) {
+  py::dict sd = model.attr("state_dict")();
+  auto has = [&](const std::string& k) { return sd.contains(py::str(k)); };
+  auto shape = [&](const std::string& k) { return py::cast<torch::Tensor>(sd[py::str(k)]).sizes().vec(); };
+  if (!has("output.weight") || !has("output.bias")) {
+    *why = "no output.weight/output.bias";
+    return false;
+  }
+  MlpHost m;
+  size_t consumed = 2;
+  for (int l = 0;; ++l) {
+    const std::string k = "body." + std::to_string(4 * l);
+    if (!has(k + ".weight")) break;
+    auto s = shape(k + ".weight");
+    if (s.size() != 2 || !has(k + ".bias")) {
+      *why = k + " is not a Linear";
+      return false;
+    }
+    if (l == 0) {
+      m.n_in = (int)s[1];
+      m.n_hidden = (int)s[0];
+    } else if ((int)s[0] != m.n_hidden || (int)s[1] != m.n_hidden) {
+      *why = "hidden layers of different widths";
+      return false;
+    }
+    m.w.push_back(to_floats(sd[py::str(k + ".weight")]));
+    m.b.push_back(to_floats(sd[py::str(k + ".bias")]));
+    consumed += 2;
+    const std::string n = "body." + std::to_string(4 * l + 1);
+    if (has(n + ".weight")) {
+      m.ln_w.push_back(to_floats(sd[py::str(n + ".weight")]));
+      m.ln_b.push_back(to_floats(sd[py::str(n + ".bias")]));
+      consumed += 2;
+    }
+    ++m.n_layers;
+  }
+  if (m.n_layers == 0) {
+    *why = "no hidden Linear layers under body.*";
+    return false;
+  }
+  if (!m.ln_w.empty() && (int)m.ln_w.size() != m.n_layers) {
+    *why = "LayerNorm on some hidden layers only";
+    return false;
+  }
+  if (consumed != sd.size()) {
+    *why = "state_dict has parameters outside the Net2 layout";
+    return false;
+  }
+  m.use_ln = !m.ln_w.empty();
+  auto so = shape("output.weight");
+  if (so.size() != 2 || (int)so[1] != m.n_hidden) {
+    *why = "output layer width mismatch";
+    return false;
+  }
+  m.n_out = (int)so[0];
+  m.w_out = to_floats(sd[py::str("output.weight")]);
+  m.b_out = to_floats(sd[py::str("output.bias")]);
+  *out = std::move(m);
+  return true;
+}
+
+int parse_device(const std::string& device) {
+  if (device.rfind("cuda", 0) != 0)
+    fail("rebel_amd.rela.ModelLocker: device '" + device +
+         "' -- this module generates on an MI355X only (no CPU path); pass 'cuda:N' (cfg: selfplay.cpu_gen_threads=0)");
+  const auto c = device.find(':');
+  return c == std::string::npos ? 0 : std::atoi(device.c_str() + c + 1);
+}
+
+class ModelLocker {
+ public:
+  ModelLocker(std::vector<py::object> models, const std::string& device)
+      : device(device), device_index(parse_device(device)), py_models_(std::move(models)) {
+    if (py_models_.empty()) fail("ModelLocker: need at least one model");
+    refresh_weights(py_models_[0]);
+  }
+
+  void update_model(py::object py_model) {  // model_locker.h:69-79
+    for (auto& m : py_models_) m.attr("load_state_dict")(py_model.attr("state_dict")());
+    refresh_weights(py_models_[0]);
+    std::lock_guard<std::mutex> lk(m_);
+    for (rbl_engine* e : engines_) apply(e);
+  }
+
+  // engines register to receive weight refreshes; called by Context.start()
+  void attach(rbl_engine* e) {
+    std::lock_guard<std::mutex> lk(m_);
+    apply(e);
+    engines_.push_back(e);
+  }
+  void detach(rbl_engine* e) {
+    std::lock_guard<std::mutex> lk(m_);
+    for (size_t i = 0; i < engines_.size(); ++i)
+      if (engines_[i] == e) {
+        engines_.erase(engines_.begin() + i);
+        break;
+      }
+  }
+
+  const std::string device;
+  const int device_index;
+
+ private:
+  void refresh_weights(const py::object& model) {
+    std::string why;
+    MlpHost m;
+    if (parse_net2(model, &m, &why)) {
+      std::lock_guard<std::mutex> lk(m_);
+      mlp_ = std::move(m);
+      is_mlp_ = true;
+    } else {  // generic TorchScript module: evaluated on the GPU through libtorch for the whole batch
+      std::lock_guard<std::mutex> lk(m_);
+      is_mlp_ = false;
+      jit_ = model.attr("_c").cast<torch::jit::Module*>();
+      generic_reason_ = why;
+    }
+  }
+
+  static void jit_forward(void* user, const float* q, int64_t rows, int64_t qs, float* out, int64_t n_out, void*) {
+    auto* self = static_cast<ModelLocker*>(user);
+    torch::NoGradGuard ng;
+    const auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, self->device_index);
+    auto qt = torch::from_blob(const_cast<float*>(q), {rows, qs}, opt);
+    auto ot = torch::from_blob(out, {rows, n_out}, opt);
+    std::vector<torch::jit::IValue> inputs = {qt};
+    ot.copy_(self->jit_->forward(inputs).toTensor().to(torch::kFloat32));
+    torch::cuda::synchronize(self->device_index);
+  }
+
+  void apply(rbl_engine* e) {  // m_ held
+    if (is_mlp_) {
+      std::vector<const float*> w, b, g, o;
+      for (int l = 0; l < mlp_.n_layers; ++l) {
+        w.push_back(mlp_.w[l].data());
+        b.push_back(mlp_.b[l].data());
+        if (mlp_.use_ln) {
+          g.push_back(mlp_.ln_w[l].data());
+          o.push_back(mlp_.ln_b[l].data());
+        }
+      }
+      rbl_mlp_weights c{};
+      c.n_layers = mlp_.n_layers;
+      c.n_in = mlp_.n_in;
+      c.n_hidden = mlp_.n_hidden;
+      c.n_out = mlp_.n_out;
+      c.use_layer_norm = mlp_.use_ln;
+      c.w = w.data();
+      c.b = b.data();
+      c.ln_w = mlp_.use_ln ? g.data() : nullptr;
+      c.ln_b = mlp_.use_ln ? o.data() : nullptr;
+      c.w_out = mlp_.w_out.data();
+      c.b_out = mlp_.b_out.data();
+      c.ln_eps = 1e-5f;
+      if (rbl_engine_set_net_mlp(e, &c) == 0) return;
+      // shape outside the fused kernel's envelope (e.g. n_hidden=512): fall through to the TorchScript forward
+      jit_ = py_models_[0].attr("_c").cast<torch::jit::Module*>();
+    }
+    // synchronous device-pointer callback: the engine stream is idle while libtorch runs (engine syncs around it)
+    check(rbl_engine_set_net_callback(e, &ModelLocker::jit_forward, this, /*host_buffers=*/0), "set_net_callback");
+  }
+
+  std::vector<py::object> py_models_;
+  std::mutex m_;
+  MlpHost mlp_;
+  bool is_mlp_ = false;
+  torch::jit::Module* jit_ = nullptr;
+  std::string generic_reason_;
+  std::vector<rbl_engine*> engines_;
+};
+
+// ------------------------------------------------------------------------------------------------ thread loops
+class ThreadLoop {  // rela/thread_loop.h:26-67 (opaque to Python)
+ public:
+  virtual ~ThreadLoop() = default;
+};
+
+// One create_cfr_thread() call = one self-play lane (or REBEL_AMD_LANES_PER_THREAD lanes, seeds seed + j*1000003).
+class DataThreadLoop : public ThreadLoop {
+ public:
+  DataThreadLoop(std::shared_ptr<ModelLocker> locker, std::shared_ptr<ValuePrioritizedReplay> replay,
+                 const RecursiveSolvingParams& cfg, int seed)
+      : locker(std::move(locker)), replay(std::move(replay)), cfg(cfg), seed(seed) {}
+  std::shared_ptr<ModelLocker> locker;
+  std::shared_ptr<ValuePrioritizedReplay> replay;
+  const RecursiveSolvingParams cfg;
+  const int seed;
+};
+
+std::shared_ptr<ThreadLoop> create_cfr_thread(std::shared_ptr<ModelLocker> locker,
+                                              std::shared_ptr<ValuePrioritizedReplay> replay,
+                                              const RecursiveSolvingParams& cfg, int seed) {  // pybind.cc:36-43
+  if (!locker || !replay) fail("create_cfr_thread: model_locker and replay must not be None");
+  return std::make_shared<DataThreadLoop>(std::move(locker), std::move(replay), cfg, seed);
+}
+
+// ------------------------------------------------------------------------------------------------ context
+class Context {  // rela/context.h:26-85
+ public:
+  Context() = default;
+  Context(const Context&) = delete;
+  ~Context() {
+    terminate();
+    join();
+  }
+
+  int push_env_thread(std::shared_ptr<ThreadLoop> loop) {
+    if (started_) fail("Context.push_env_thread: context already started");
+    auto lane = std::dynamic_pointer_cast<DataThreadLoop>(loop);
+    if (!lane) fail("Context.push_env_thread: expected a loop made by create_cfr_thread");
+    lanes_.push_back(std::move(lane));
+    return (int)lanes_.size();
+  }
+
+  void start() {
+    if (started_) return;
+    started_ = true;
+    const char* lpt = std::getenv("REBEL_AMD_LANES_PER_THREAD");
+    const int per = std::max(1, lpt && *lpt ? std::atoi(lpt) : 1);
+    // group lanes that can share an engine
+    for (auto& lane : lanes_) {
+      Worker* w = nullptr;
+      for (auto& c : workers_)
+        if (c->locker == lane->locker && c->replay == lane->replay && same(c->cfg, lane->cfg)) w = c.get();
+      if (!w) {
+        workers_.push_back(std::make_unique<Worker>());
+        w = workers_.back().get();
+        w->locker = lane->locker;
+        w->replay = lane->replay;
+        w->cfg = lane->cfg;
+      }
+      for (int j = 0; j < per; ++j) w->seeds.push_back(lane->seed + j * 1000003);
+      ++w->n_loops;
+    }
+    for (auto& w : workers_) {  // engines are created here so that configuration errors surface as Python exceptions
+      const rbl_params p = to_c(w->cfg.subgame_params);
+      w->engine = rbl_engine_create(w->locker->device_index, w->cfg.num_dice, w->cfg.num_faces, &p, (int)w->seeds.size());
+      if (!w->engine) fail(std::string("Context.start: ") + rbl_last_error());
+      w->locker->attach(w->engine);
+      w->sp = rbl_selfplay_create(w->engine, (int)w->seeds.size(), w->seeds.data(), w->cfg.random_action_prob,
+                                  w->cfg.sample_leaf);
+      if (!w->sp) fail(std::string("Context.start: ") + rbl_last_error());
+    }
+    for (auto& w : workers_) {
+      Worker* wp = w.get();
+      wp->thread = std::thread([this, wp] { run(wp); });
+    }
+  }
+
+  void pause() {
+    std::lock_guard<std::mutex> lk(m_pause_);
+    paused_ = true;
+  }
+  void resume() {
+    {
+      std::lock_guard<std::mutex> lk(m_pause_);
+      paused_ = false;
+    }
+    cv_pause_.notify_all();
+  }
+  void terminate() {
+    stop_ = true;
+    resume();
+  }
+  bool terminated() {
+    int done = 0, total = 0;
+    for (auto& w : workers_) {
+      total += w->n_loops;
+      if (w->done) done += w->n_loops;
+    }
+    if (!started_) return lanes_.empty();
+    return done == total;
+  }
+
+ private:
+  struct Worker {
+    std::shared_ptr<ModelLocker> locker;
+    std::shared_ptr<ValuePrioritizedReplay> replay;
+    RecursiveSolvingParams cfg;
+    std::vector<int32_t> seeds;
+    int n_loops = 0;
+    rbl_engine* engine = nullptr;
+    rbl_selfplay* sp = nullptr;
+    std::thread thread;
+    std::atomic<bool> done{false};
+    const std::atomic<bool>* stop = nullptr;
+    std::vector<float> ones;
+  };
+
+  static void sink(void* user, int64_t n, const int32_t*, const float* q, int64_t qs, const float* v, int64_t vs) {
+    auto* w = static_cast<Worker*>(user);  // CVNetBufferConnector::add_training_example (rela/data_loop.h:50-55)
+    if ((int64_t)w->ones.size() < n) w->ones.assign(n, 1.0f);
+    w->replay->add_block(q, qs, v, vs, n, w->ones.data(), w->stop);
+  }
+
+  void run(Worker* w) {  // DataThreadLoop::mainLoop (rela/data_loop.h:67-76), all lanes of the engine at once
+    w->stop = &stop_;
+    try {
+      while (!stop_) {
+        {
+          std::unique_lock<std::mutex> lk(m_pause_);
+          cv_pause_.wait(lk, [this] { return !paused_ || stop_; });
+        }
+        if (stop_) break;
+        if (rbl_selfplay_advance(w->sp, &Context::sink, w) < 0) fail(rbl_last_error());
+      }
+    } catch (const std::exception& ex) {
+      std::fprintf(stderr, "rebel_amd.rela: generator stopped: %s\n", ex.what());
+    }
+    w->done = true;
+  }
+
+  void join() {
+    for (auto& w : workers_) {
+      if (w->thread.joinable()) w->thread.join();
+      if (w->sp) rbl_selfplay_destroy(w->sp);
+      if (w->engine) {
+        w->locker->detach(w->engine);
+        rbl_engine_destroy(w->engine);
+      }
+      w->sp = nullptr;
+      w->engine = nullptr;
+    }
+  }
+
+  bool started_ = false;
+  std::atomic<bool> stop_{false};
+  std::mutex m_pause_;
+  std::condition_variable cv_pause_;
+  bool paused_ = false;
+  std::vector<std::shared_ptr<DataThreadLoop>> lanes_;
+  std::vector<std::unique_ptr<Worker>> workers_;
+};
+
+[[noreturn]] void eval_not_built(const char* name) {
+  fail(std::string("rebel_amd.rela.") + name +
+       ": full-tree evaluation (best-response / exploitability sweep) is not part of the MI355X data-generation path "
+       "yet (DESIGN.md, 'next' rows); use the reference build for evaluation");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(rela, m) {
+  m.doc() = "MI355X-native drop-in for cfvpy.rela (ReBeL Liar's Dice data generation)";
+
+  py::class_<ValueTransition, std::shared_ptr<ValueTransition>>(m, "ValueTransition")
+      .def(py::init<>())
+      .def_readwrite("query", &ValueTransition::query)
+      .def_readwrite("values", &ValueTransition::values);
+
+  py::class_<ValuePrioritizedReplay, std::shared_ptr<ValuePrioritizedReplay>>(m, "ValuePrioritizedReplay")
+      .def(py::init<int, int, float, float, int, bool, bool>(), py::arg("capacity"), py::arg("seed"), py::arg("alpha"),
+           py::arg("beta"), py::arg("prefetch"), py::arg("use_priority"), py::arg("compressed_values"))
+      .def("size", &ValuePrioritizedReplay::size)
+      .def("num_add", &ValuePrioritizedReplay::num_add)
+      .def("sample", &ValuePrioritizedReplay::sample)
+      .def("pop_until", &ValuePrioritizedReplay::pop_until)
+      .def("load", &ValuePrioritizedReplay::load)
+      .def("save", &ValuePrioritizedReplay::save)
+      .def("extract", &ValuePrioritizedReplay::extract)
+      .def("push", &ValuePrioritizedReplay::push, py::call_guard<py::gil_scoped_release>())
+      .def("update_priority", &ValuePrioritizedReplay::update_priority);
+
+  py::class_<ThreadLoop, std::shared_ptr<ThreadLoop>>(m, "ThreadLoop");
+
+  py::class_<SubgameSolvingParams>(m, "SubgameSolvingParams")
+      .def(py::init<>())
+      .def_readwrite("num_iters", &SubgameSolvingParams::num_iters)
+      .def_readwrite("max_depth", &SubgameSolvingParams::max_depth)
+      .def_readwrite("linear_update", &SubgameSolvingParams::linear_update)
+      .def_readwrite("optimistic", &SubgameSolvingParams::optimistic)
+      .def_readwrite("use_cfr", &SubgameSolvingParams::use_cfr)
+      .def_readwrite("dcfr", &SubgameSolvingParams::dcfr)
+      .def_readwrite("dcfr_alpha", &SubgameSolvingParams::dcfr_alpha)
+      .def_readwrite("dcfr_beta", &SubgameSolvingParams::dcfr_beta)
+      .def_readwrite("dcfr_gamma", &SubgameSolvingParams::dcfr_gamma);
+
+  py::class_<RecursiveSolvingParams>(m, "RecursiveSolvingParams")
+      .def(py::init<>())
+      .def_readwrite("num_dice", &RecursiveSolvingParams::num_dice)
+      .def_readwrite("num_faces", &RecursiveSolvingParams::num_faces)
+      .def_readwrite("random_action_prob", &RecursiveSolvingParams::random_action_prob)
+      .def_readwrite("sample_leaf", &RecursiveSolvingParams::sample_leaf)
+      .def_readwrite("subgame_params", &RecursiveSolvingParams::subgame_params);
+
+  // The reference registers DataThreadLoop with a constructor over CVNetBufferConnector, a type it never exposes to
+  // Python (pybind.cc:177-181), so the class is a handle type in practice; same here.
+  py::class_<DataThreadLoop, ThreadLoop, std::shared_ptr<DataThreadLoop>>(m, "DataThreadLoop");
+
+  py::class_<Context>(m, "Context")
+      .def(py::init<>())
+      .def("push_env_thread", &Context::push_env_thread, py::keep_alive<1, 2>())
+      .def("start", &Context::start)
+      .def("pause", &Context::pause)
+      .def("resume", &Context::resume)
+      .def("terminate", &Context::terminate)
+      .def("terminated", &Context::terminated);
+
+  py::class_<ModelLocker, std::shared_ptr<ModelLocker>>(m, "ModelLocker")
+      .def(py::init<std::vector<py::object>, const std::string&>())
+      .def("update_model", &ModelLocker::update_model);
+
+  m.def("compute_exploitability_fp",
+        [](const RecursiveSolvingParams&) -> float { eval_not_built("compute_exploitability_fp"); }, py::arg("params"));
+  m.def("compute_exploitability_with_net",
+        [](const RecursiveSolvingParams&, const std::string&) -> float {
+          eval_not_built("compute_exploitability_with_net");
+        },
+        py::arg("params"), py::arg("model_path"));
+  m.def("compute_stats_with_net",
+        [](const RecursiveSolvingParams&, const std::string&) -> std::tuple<float, float, float> {
+          eval_not_built("compute_stats_with_net");
+        },
+        py::arg("params"), py::arg("model_path"));
+
+  m.def("create_cfr_thread", &create_cfr_thread, py::arg("model_locker"), py::arg("replay"), py::arg("cfg"),
+        py::arg("seed"));
+}

@@ -1,0 +1,21 @@
+"""Multi-GPU layout of the data-generation job: games are independent (each lane owns its state, RNG and solver --
+recursive_solving.h:73-85 in the reference), so GPUs get disjoint lane/seed ranges and there is NO data-path
+collective; the only cross-rank traffic is the scalar bookkeeping of a benchmark (max time, summed work)."""
+
+
+def lane_seeds(rank, lanes_per_gpu):
+    """Disjoint seeds per rank.  (The reference's convention rank*1000+i, selfplay.py:250, collides above 1000 lanes.)"""
+    return [rank * lanes_per_gpu + i for i in range(lanes_per_gpu)]
+
+
+def reduce_job(dist, world, dt, units, games, device="cuda"):
+    """-> (max over ranks of dt, sum of units, sum of games)"""
+    if world <= 1:
+        return dt, units, games
+    import torch
+
+    tot = torch.tensor([dt, units, games], dtype=torch.float64, device=device)
+    mx = tot.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    return mx[0].item(), tot[1].item(), tot[2].item()

@@ -1,0 +1,161 @@
+"""GPU test of the drop-in boundary: the exact call sequence of the reference trainer's data-generation setup
+(cfvpy/selfplay.py:182-260 `initialize_datagen`, :283 `context.start()`, :509-512 `update_model`, :416 `replay.sample`)
+against `rebel_amd.rela`, with the reference's own TimedContext subclassing pattern (cfvpy/utils.py:73-95)."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(rela, d, f, iters):
+    cfg = rela.RecursiveSolvingParams()
+    for k, v in dict(num_dice=d, num_faces=f, random_action_prob=0.25, sample_leaf=True).items():
+        assert hasattr(cfg, k)
+        setattr(cfg, k, v)
+    for k, v in dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True).items():
+        setattr(cfg.subgame_params, k, v)
+    return cfg
+
+
+def _wait(pred, timeout=120):
+    t0 = time.time()
+    while not pred():
+        assert time.time() - t0 < timeout, "timed out"
+        time.sleep(0.05)
+
+
+def test_initialize_datagen_sequence():
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    d, f, iters, lanes = 1, 6, 64, 96
+    torch.manual_seed(0)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+    ref_model = torch.jit.script(net.to("cuda:0")).eval()
+    locker = rela.ModelLocker([ref_model], "cuda:0")
+    replay = rela.ValuePrioritizedReplay(capacity=2 ** 16, seed=10001, alpha=1.0, beta=0.4, prefetch=3,
+                                         use_priority=True, compressed_values=False)
+
+    class TimedContext(rela.Context):
+        def __init__(self):
+            super().__init__()
+            self.t0 = None
+
+        def start(self):
+            super().start()
+            self.t0 = time.time()
+
+    ctx = TimedContext()
+    cfg = _cfg(rela, d, f, iters)
+    for i in range(lanes):
+        ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, i))
+    ctx.start()
+    _wait(lambda: replay.size() >= 4 * lanes)
+    assert replay.num_add() % (2 * lanes) == 0  # whole epochs: 2 examples per lane per subgame
+
+    batch, weights = replay.sample(64, "cuda:0")
+    assert batch.query.shape == (64, 27) and batch.values.shape == (64, 6) and weights.shape == (64,)
+    assert batch.query.device.type == "cuda" and torch.isfinite(batch.values).all()
+    q = batch.query.cpu().numpy()
+    assert set(np.unique(q[:, :2])) <= {0.0, 1.0}
+    assert np.allclose(q[:, 15:21].sum(1), 1, atol=1e-5) and np.allclose(q[:, 21:27].sum(1), 1, atol=1e-5)
+    replay.update_priority(torch.ones(64))
+
+    # pause / resume (selfplay.py uses them around checkpoints)
+    ctx.pause()
+    time.sleep(0.5)
+    n0 = replay.num_add()
+    time.sleep(0.5)
+    assert replay.num_add() - n0 <= 2 * lanes  # at most the epoch in flight lands
+    ctx.resume()
+
+    # weight sync: outputs scaled x5 must show up in the generated root values
+    with torch.no_grad():
+        net2 = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+        net2.load_state_dict(net.state_dict())
+        net2.output.weight *= 50
+        net2.output.bias *= 50
+    locker.update_model(net2)
+    assert torch.equal(ref_model.state_dict()["output.bias"].cpu(), net2.state_dict()["output.bias"])
+    n1 = replay.num_add()
+    _wait(lambda: replay.num_add() >= n1 + 6 * lanes)
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    data = replay.extract()
+    qs, vs = data[0].numpy(), data[1].numpy()
+    root = qs[:, 2:15].sum(1) == 0  # root-state examples: all-zero last-bid one-hot
+    assert root.any()
+    first = np.abs(vs[root][:lanes]).max()
+    last = np.abs(vs[root][-lanes:]).max()
+    assert last > 5 * first, (first, last)  # the refreshed (x50) weights reached the engine
+
+
+def test_generic_torchscript_module_runs_on_gpu():
+    """A value net that is NOT Net2-shaped still works: its TorchScript forward is evaluated on the GPU per batch."""
+    import torch
+
+    import rebel_amd.rela as rela
+
+    class Odd(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(19, 40)
+            self.b = torch.nn.Linear(40, 4)
+
+        def forward(self, x):
+            return torch.tanh(self.b(torch.relu(self.a(x)))) * 0.1
+
+    torch.manual_seed(1)
+    m = torch.jit.script(Odd().to("cuda:0")).eval()
+    locker = rela.ModelLocker([m], "cuda:0")
+    replay = rela.ValuePrioritizedReplay(capacity=4096, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    ctx = rela.Context()
+    cfg = _cfg(rela, 1, 4, 16)
+    for i in range(8):
+        ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, i))
+    ctx.start()
+    _wait(lambda: replay.size() >= 32)
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    t, _ = replay.sample(16, "cpu")
+    assert torch.isfinite(t.values).all() and t.values.abs().max() > 0
+
+
+def test_rela_lane_matches_capi_lane():
+    """The examples a rela lane pushes are exactly those of the C-ABI self-play lane with the same seed."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd import capi
+    from rebel_amd.models import Net2, mlp_weights_from_state_dict
+
+    d, f, iters = 1, 4, 32
+    torch.manual_seed(3)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+    e = capi.Engine(d, f, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), max_lanes=1)
+    e.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
+    sp = capi.SelfPlay(e, [42])
+    want_q, want_v = [], []
+    for _ in range(6):
+        _, _, q, v = sp.advance()
+        want_q.append(q)
+        want_v.append(v)
+    want_q, want_v = np.concatenate(want_q), np.concatenate(want_v)
+
+    m = torch.jit.script(net.to("cuda:0")).eval()
+    locker = rela.ModelLocker([m], "cuda:0")
+    replay = rela.ValuePrioritizedReplay(capacity=4096, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    ctx = rela.Context()
+    ctx.push_env_thread(rela.create_cfr_thread(locker, replay, _cfg(rela, d, f, iters), 42))
+    ctx.start()
+    _wait(lambda: replay.size() >= 12)
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    data = replay.extract()
+    assert np.array_equal(data[0].numpy()[:12], want_q) and np.array_equal(data[1].numpy()[:12], want_v)
