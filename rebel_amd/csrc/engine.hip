@@ -134,8 +134,9 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   if (w.n_out != g_.H)
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
+  const int tile = env_int("RBL_MLP_TILE", 16) == 32 ? 32 : 16;
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
-                          w.w_out, w.b_out);
+                          w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches on the engine stream
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   d_mlp_blob_.upload(pk.blob, stream_);
@@ -146,6 +147,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   mlp_.n_hidden = w.n_hidden;
   mlp_.n_out = w.n_out;
   mlp_.use_ln = w.use_layer_norm;
+  mlp_.tile = pk.tile;
   mlp_.k0_steps = pk.k0_steps;
   mlp_.out_tiles = pk.out_tiles;
   mlp_.ln_eps = w.ln_eps > 0 ? w.ln_eps : 1e-5f;

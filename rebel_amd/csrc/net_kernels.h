@@ -10,6 +10,7 @@ namespace rbl {
 // Device-resident, MFMA-ready copy of a Net2 (cfvpy/models.py:64-94).  Built by pack_mlp() from torch-layout weights.
 struct MlpDev {
   int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
+  int tile = 16;      // MFMA tile: 16 (v_mfma_f32_16x16x4_f32, default) or 32 (v_mfma_f32_32x32x2_f32)
   int k0_steps = 0;   // layer-0 k-pairs, padded to a multiple of 4
   int out_tiles = 0;  // ceil(n_out / 32)
   float ln_eps = 1e-5f;
@@ -26,11 +27,11 @@ struct MlpDev {
 struct MlpPacked {
   std::vector<float> blob;
   size_t off_w0, off_wh, off_wo, off_bias, off_lnw, off_lnb, off_bout;
-  int k0_steps, out_tiles;
+  int k0_steps, out_tiles, tile;
 };
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
-                   const float* b_out);
+                   const float* b_out, int tile);
 
 bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
 
