@@ -58,6 +58,21 @@ __device__ __forceinline__ float gelu_erf(float x) {  // torch.nn.functional.gel
   return 0.5f * x * (1.0f + erf_nobranch(x * 0.70710678118654752440f));
 }
 
+
+// The two waves that share a SIMD otherwise march in phase (fair arbitration keeps them aligned), so their MFMA phases
+// collide and their LayerNorm/GELU (VALU) phases collide, leaving the matrix pipe idle ~40 % of the time.  A static
+// priority on one of them (hardware wave-slot parity) makes the favoured wave own the matrix pipe during its MFMA phase
+// while the other one fills the favoured wave's VALU phases -- the two fall into anti-phase.
+__device__ __forceinline__ void stagger_priority() {
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID.wave_id
+  if (slot & 1) __builtin_amdgcn_s_setprio(1);
+}
+// experiment: one-time start delay of ~half a tile period for half of the FIRST round of waves
+__device__ __forceinline__ void stagger_sleep(bool first_round_odd, int n) {
+  if (first_round_odd)
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // bias + LayerNorm + GELU on a register-resident [32 rows x 32*NT features] tile, in place.
 template <int NT>
 __device__ __forceinline__ void epilogue(f32x16 (&acc)[NT], const float* __restrict__ bias,
@@ -192,31 +207,69 @@ __global__ void __launch_bounds__(64) mlp_forward_kernel(const MlpDev m, const f
 // next layer.  Half the registers of the 32x32 form (64 + 64 accumulators for n_hidden = 256), so 2-3 waves fit per SIMD
 // and one wave's LayerNorm/GELU epilogue (VALU) overlaps the other waves' MFMAs; the price is 2x the weight traffic
 // from L2 per row, which the extra resident waves hide.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+// GELU(x) = 0.5 x (1 + erf(x / sqrt2)) on two elements at once, written so that hipcc emits packed f32 math
+// (v_pk_fma_f32 / v_pk_mul_f32): f32-input MFMA runs on the same FMA lanes as the f32 VALU (equal rate, §MI355X
+// guide), so epilogue VALU time ADDS to MFMA time instead of hiding under it -- every VALU issue slot counts.
+// erf: the two classic minimax branches (|z| <= 0.9277: z + z P(z^2); else 1 - exp(R(|z|))), both evaluated, selected
+// per element; R is pre-scaled by log2(e) so that exp() is a single v_exp_f32.  Max |error| of the result ~1e-7.
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  constexpr float kL2E = 1.44269504088896340736f;
+  const f32x2 hx = x * splat2(0.5f);
+  const f32x2 z = x * splat2(0.70710678118654752440f);
+  const f32x2 s = z * z;
+  const f32x2 t = __builtin_elementwise_abs(z);
+  // small branch: erf = z + z * P(s)
+  f32x2 p = splat2(-5.96761703e-4f);
+  p = fma2(p, s, splat2(4.99119423e-3f));
+  p = fma2(p, s, splat2(-2.67681349e-2f));
+  p = fma2(p, s, splat2(1.12819925e-1f));
+  p = fma2(p, s, splat2(-3.76125336e-1f));
+  p = fma2(p, s, splat2(1.28379166e-1f));
+  const f32x2 small = fma2(hx, fma2(z, p, z), hx);  // 0.5x + 0.5x * erf
+  // large branch: erf = sign(z) (1 - 2^r),  r = log2e * (R(t) t - t)
+  f32x2 r = fma2(splat2(-1.72853470e-5f * kL2E), t, splat2(3.83197126e-4f * kL2E));
+  const f32x2 u = fma2(splat2(-3.88396438e-3f * kL2E), t, splat2(2.42546219e-2f * kL2E));
+  r = fma2(r, s, u);
+  r = fma2(r, t, splat2(-1.06777877e-1f * kL2E));
+  r = fma2(r, t, splat2(-6.34846687e-1f * kL2E));
+  r = fma2(r, t, splat2(-1.28717512e-1f * kL2E));
+  r = (r - splat2(kL2E)) * t;
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
+  const f32x2 large = fma2(__builtin_elementwise_abs(hx), splat2(1.0f) - e, hx);  // 0.5x + 0.5|x| (1 - e)
+  return f32x2{t[0] > 0.927734375f ? large[0] : small[0], t[1] > 0.927734375f ? large[1] : small[1]};
+}
+
+// bias + LayerNorm + GELU on a register-resident [16 rows x 16*NT features] tile, in place (packed f32 math).
 template <int NT>
 __device__ __forceinline__ void epilogue16(f32x4 (&acc)[NT], const float* __restrict__ bias,
                                            const float* __restrict__ ln_w, const float* __restrict__ ln_b, int use_ln,
                                            float eps, int g) {
+  if (use_ln == 2) return;  // timing experiment only (RBL_MLP_DEBUG=1): no bias / LayerNorm / GELU
   constexpr float inv_n = 1.0f / (16 * NT);
+  f32x2 s2 = splat2(0.f);
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + it * 16 + 4 * g);
-    acc[it] += b4;
+    acc[it] += *reinterpret_cast<const f32x4*>(bias + it * 16 + 4 * g);
+    s2 += f32x2{acc[it][0], acc[it][1]} + f32x2{acc[it][2], acc[it][3]};
   }
   if (use_ln) {
-    float s = 0.f;
-#pragma unroll
-    for (int it = 0; it < NT; ++it) s += (acc[it][0] + acc[it][1]) + (acc[it][2] + acc[it][3]);
+    float s = s2[0] + s2[1];
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
     const float mean = s * inv_n;
-    float vs = 0.f;
+    f32x2 v2 = splat2(0.f);
 #pragma unroll
-    for (int it = 0; it < NT; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float d = acc[it][r] - mean;
-        vs = fmaf(d, d, vs);
-      }
+    for (int it = 0; it < NT; ++it) {
+      const f32x2 d0 = f32x2{acc[it][0], acc[it][1]} - splat2(mean), d1 = f32x2{acc[it][2], acc[it][3]} - splat2(mean);
+      v2 = fma2(d0, d0, v2);
+      v2 = fma2(d1, d1, v2);
+    }
+    float vs = v2[0] + v2[1];
     vs += __shfl_xor(vs, 16);
     vs += __shfl_xor(vs, 32);
     const float rstd = 1.0f / sqrtf(vs * inv_n + eps);
@@ -225,13 +278,24 @@ __device__ __forceinline__ void epilogue16(f32x4 (&acc)[NT], const float* __rest
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_w + it * 16 + 4 * g);
       const f32x4 o4 = *reinterpret_cast<const f32x4*>(ln_b + it * 16 + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[it][r] = (acc[it][r] - mean) * rstd * g4[r] + o4[r];
+      for (int h = 0; h < 2; ++h) {  // (x - mean) * rstd * gamma + beta  ==  x * a + (beta - mean * a)
+        const f32x2 a = f32x2{g4[2 * h], g4[2 * h + 1]} * splat2(rstd);
+        const f32x2 b = fma2(splat2(-mean), a, f32x2{o4[2 * h], o4[2 * h + 1]});
+        const f32x2 y = gelu2(fma2(f32x2{acc[it][2 * h], acc[it][2 * h + 1]}, a, b));
+        acc[it][2 * h] = y[0];
+        acc[it][2 * h + 1] = y[1];
+      }
     }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 y = gelu2(f32x2{acc[it][2 * h], acc[it][2 * h + 1]});
+        acc[it][2 * h] = y[0];
+        acc[it][2 * h + 1] = y[1];
+      }
   }
-#pragma unroll
-  for (int it = 0; it < NT; ++it)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[it][r] = gelu_erf(acc[it][r]);
 }
 
 // out[it] = W-tile(it, :) . x.  Two output tiles are in flight so that dependent MFMAs are 64 cycles apart (dependent
@@ -282,6 +346,11 @@ __device__ __forceinline__ void dense16(const f32x4 (&x)[NT], f32x4 (&out)[OTILE
 template <int NT, int OT>
 __global__ void __launch_bounds__(64, 2) mlp16_forward_kernel(const MlpDev m, const float* __restrict__ queries,
                                                            int64_t rows, float* __restrict__ out) {
+  if (m.stagger == 1) stagger_priority();
+  if (m.stagger >= 2) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    stagger_sleep(blockIdx.x < 2048 && (slot & 1), m.stagger);
+  }
   const int lane = threadIdx.x;
   const int j = lane & 15, g = lane >> 4;
   const int64_t row = (int64_t)blockIdx.x * 16 + j;
@@ -320,6 +389,141 @@ __global__ void __launch_bounds__(64, 2) mlp16_forward_kernel(const MlpDev m, co
   {
     f32x4 o[OT];
     dense16<NT, OT>(x, o, reinterpret_cast<const f32x4*>(m.wo), lane);
+    if (valid) {
+      float* orow = out + row * m.n_out;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ot * 16 + 4 * g + r;
+          if (i < m.n_out) orow[i] = o[ot][r] + m.b_out[i];
+        }
+    }
+  }
+}
+
+
+// ================================================================================================ LDS weight-tape variant
+// n_hidden = 256 (the reference's net): 4 waves x 16 rows per workgroup share ONE copy of the weights.  The packed
+// weights of the whole net form a linear "tape" that every wave consumes strictly in order (layer 0 by k-group, hidden
+// layers by output-tile pair, output layer by tile pair), so the tape is streamed through a 2 x 32 KiB LDS ring with
+// global_load_lds_dwordx4 (asynchronous, no VGPR staging), one 32 KiB chunk ahead of the MFMAs.  L2->CU weight traffic
+// drops 4x versus every wave fetching its own fragments, and a load is in flight for a whole chunk (>= 4k cycles of
+// MFMA issue) before it is needed.  Two workgroups per CU (2 waves/SIMD) run at different phases, so one's
+// LayerNorm/GELU epilogue overlaps the other's MFMAs.
+constexpr int kChunkF4 = 2048;  // float4 per chunk (32 KiB)
+
+template <int OT>
+__global__ void __launch_bounds__(256, 2) mlp_tape_forward_kernel(const MlpDev m, const float* __restrict__ queries,
+                                                                  int64_t rows, float* __restrict__ out) {
+  constexpr int NT = 16;
+  __shared__ f32x4 ring[2 * kChunkF4];
+  if (m.stagger == 1) stagger_priority();
+  if (m.stagger >= 2) stagger_sleep(blockIdx.x >= 256 && blockIdx.x < 512, m.stagger);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
+  const bool valid = row < rows;
+  const float* qrow = queries + (valid ? row : 0) * m.n_in;
+  const f32x4* tape = reinterpret_cast<const f32x4*>(m.tape);
+  const int nchunks = m.tape_chunks;
+
+  // each wave moves 8 KiB of every chunk: 8 wave-instructions of 1 KiB (LDS destination = uniform base + lane*16)
+  auto issue = [&](int c) {
+    if (c < nchunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int off = (wave * 8 + i) * 64;
+        __builtin_amdgcn_global_load_lds(tape + (size_t)c * kChunkF4 + off + lane, &ring[(c & 1) * kChunkF4 + off], 16, 0,
+                                         0);
+      }
+    }
+  };
+  issue(0);
+  issue(1);
+  int c = 0;
+
+  f32x4 x[NT];
+#pragma unroll
+  for (int it = 0; it < NT; ++it) x[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---------------------------------------------------------------- layer 0: two k-groups (32 inputs) per chunk
+  for (int c0 = 0; c0 < m.l0_chunks; ++c0, ++c) {
+    float b[2][4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int k = 16 * (2 * c0 + s2) + 4 * jj + g;
+        b[s2][jj] = (valid && k < m.n_in) ? qrow[k] : 0.f;
+      }
+    __syncthreads();  // chunk c landed (hipcc drains vmcnt before the barrier) and is visible to every wave
+    const f32x4* buf = &ring[(c & 1) * kChunkF4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int it = 0; it < NT; ++it) {
+        const f32x4 a4 = buf[(s2 * NT + it) * 64 + lane];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) x[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[jj], b[s2][jj], x[it], 0, 0, 0);
+      }
+    __syncthreads();  // every wave is done reading the buffer before it is refilled
+    issue(c + 2);
+  }
+  epilogue16<NT>(x, m.bias, m.ln_w, m.ln_b, m.use_ln, m.ln_eps, g);
+
+  // one chunk = the 2 x 16 weight fragments of an output-tile pair; fragments ride a 2-step register ring from LDS
+  auto pair_from_lds = [&](const f32x4* buf, f32x4& a, f32x4& bb) {
+    constexpr int PF = 2;
+    f32x4 ra[PF], rb[PF];
+#pragma unroll
+    for (int t = 0; t < PF; ++t) {
+      ra[t] = buf[t * 64 + lane];
+      rb[t] = buf[(NT + t) * 64 + lane];
+    }
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    bb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const int slot = kt % PF;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[slot][r], x[kt][r], a, 0, 0, 0);
+        bb = __builtin_amdgcn_mfma_f32_16x16x4f32(rb[slot][r], x[kt][r], bb, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + PF < NT) {
+        ra[slot] = buf[(kt + PF) * 64 + lane];
+        rb[slot] = buf[(NT + kt + PF) * 64 + lane];
+      }
+    }
+  };
+
+  // ---------------------------------------------------------------- hidden layers: 8 chunks each
+  for (int l = 1; l < m.n_layers; ++l) {
+    f32x4 y[NT];
+#pragma unroll
+    for (int ip = 0; ip < NT / 2; ++ip, ++c) {
+      __syncthreads();
+      pair_from_lds(&ring[(c & 1) * kChunkF4], y[2 * ip], y[2 * ip + 1]);
+      __syncthreads();
+      issue(c + 2);
+    }
+    epilogue16<NT>(y, m.bias + l * 16 * NT, m.ln_w + l * 16 * NT, m.ln_b + l * 16 * NT, m.use_ln, m.ln_eps, g);
+#pragma unroll
+    for (int it = 0; it < NT; ++it) x[it] = y[it];
+  }
+  // ---------------------------------------------------------------- output layer (tile pairs; a lone last tile is
+  // followed by a zero tile on the tape)
+  {
+    f32x4 o[2 * ((OT + 1) / 2)];
+#pragma unroll
+    for (int op = 0; op < (OT + 1) / 2; ++op, ++c) {
+      __syncthreads();
+      pair_from_lds(&ring[(c & 1) * kChunkF4], o[2 * op], o[2 * op + 1]);
+      __syncthreads();
+      issue(c + 2);
+    }
     if (valid) {
       float* orow = out + row * m.n_out;
 #pragma unroll
@@ -392,12 +596,70 @@ static MlpPacked pack_mlp16(int n_layers, int n_in, int n_hidden, int n_out, int
   return p;
 }
 
+// tape layout (tile = 0): [layer 0: k-group pairs, [sg][it][lane][4], sg padded to even] [hidden layers: [it][kt][lane][4]]
+// [output: tile pairs [ot][kt][lane][4], ot padded to even], i.e. exactly the order the kernel consumes 32 KiB chunks in.
+static MlpPacked pack_mlp_tape(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
+                               const float* const* b, const float* const* ln_w, const float* const* ln_b,
+                               const float* w_out, const float* b_out) {
+  MlpPacked p;
+  p.tile = 0;
+  const int NT = 16;
+  const int sgn = ((n_in + 15) / 16 + 1) / 2 * 2;  // k-groups of 16 inputs, padded to an even count
+  p.k0_steps = sgn * 4;
+  p.out_tiles = (n_out + 15) / 16;
+  const int otp = (p.out_tiles + 1) / 2 * 2;
+  const size_t n_w0 = (size_t)sgn * NT * 64 * 4;
+  const size_t n_wh = (size_t)(n_layers - 1) * NT * NT * 64 * 4;
+  const size_t n_wo = (size_t)otp * NT * 64 * 4;
+  p.off_w0 = 0;
+  p.off_wh = p.off_w0 + n_w0;
+  p.off_wo = p.off_wh + n_wh;
+  p.off_bias = p.off_wo + n_wo;
+  p.off_lnw = p.off_bias + (size_t)n_layers * n_hidden;
+  p.off_lnb = p.off_lnw + (size_t)n_layers * n_hidden;
+  p.off_bout = p.off_lnb + (size_t)n_layers * n_hidden;
+  p.blob.assign(p.off_bout + (size_t)otp * 16, 0.f);
+  p.l0_chunks = sgn / 2;
+  p.tape_chunks = (int)(p.off_bias / (2048 * 4));
+  float* w0 = p.blob.data() + p.off_w0;
+  for (int sg = 0; sg < sgn; ++sg)
+    for (int it = 0; it < NT; ++it)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 4; ++jj) {
+          const int k = 16 * sg + 4 * jj + (lane >> 4), i = it * 16 + (lane & 15);
+          w0[(((size_t)sg * NT + it) * 64 + lane) * 4 + jj] = k < n_in ? w[0][(size_t)i * n_in + k] : 0.f;
+        }
+  auto pack_hidden = [&](float* dst, const float* W, int out_tiles, int n_rows) {
+    for (int it = 0; it < out_tiles; ++it)
+      for (int kt = 0; kt < NT; ++kt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int r = 0; r < 4; ++r) {
+            const int f = kt * 16 + 4 * (lane >> 4) + r;
+            const int i = it * 16 + (lane & 15);
+            dst[(((size_t)it * NT + kt) * 64 + lane) * 4 + r] = i < n_rows ? W[(size_t)i * n_hidden + f] : 0.f;
+          }
+  };
+  for (int l = 1; l < n_layers; ++l)
+    pack_hidden(p.blob.data() + p.off_wh + (size_t)(l - 1) * NT * NT * 64 * 4, w[l], NT, n_hidden);
+  pack_hidden(p.blob.data() + p.off_wo, w_out, p.out_tiles, n_out);
+  for (int l = 0; l < n_layers; ++l)
+    for (int i = 0; i < n_hidden; ++i) {
+      p.blob[p.off_bias + (size_t)l * n_hidden + i] = b[l][i];
+      p.blob[p.off_lnw + (size_t)l * n_hidden + i] = use_ln ? ln_w[l][i] : 1.f;
+      p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? ln_b[l][i] : 0.f;
+    }
+  for (int i = 0; i < n_out; ++i) p.blob[p.off_bout + i] = b_out[i];
+  return p;
+}
+
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error("value net shape not supported by the MFMA forward (n_hidden in {64,128,256}, n_out <= 64)");
-  if (tile == 16) return pack_mlp16(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
+  if (tile == 0 && n_hidden == 256 && n_out <= 64)
+    return pack_mlp_tape(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
+  if (tile != 32) return pack_mlp16(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   MlpPacked p;
   p.tile = 32;
   const int NT = n_hidden / 32;
@@ -475,6 +737,17 @@ static void launch_mlp16(const MlpDev& m, const float* queries, int64_t rows, fl
 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
   if (rows <= 0) return;
+  if (m.tile == 0) {
+    const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    switch (m.out_tiles) {
+      case 1: hipLaunchKernelGGL(mlp_tape_forward_kernel<1>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 2: hipLaunchKernelGGL(mlp_tape_forward_kernel<2>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 3: hipLaunchKernelGGL(mlp_tape_forward_kernel<3>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 4: hipLaunchKernelGGL(mlp_tape_forward_kernel<4>, grid, block, 0, stream, m, queries, rows, out); break;
+      default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+    }
+    return;
+  }
   if (m.tile == 16) return launch_mlp16(m, queries, rows, out, stream);
   const dim3 grid((unsigned)((rows + 31) / 32)), block(64);
   const int NT = m.n_hidden / 32;
