@@ -134,7 +134,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   if (w.n_out != g_.H)
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
-  const int tile = env_int("RBL_MLP_TILE", 0);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
+  const int tile = env_int("RBL_MLP_TILE", 2);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches on the engine stream
@@ -148,7 +148,8 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   mlp_.n_out = w.n_out;
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
   mlp_.tile = pk.tile;
-  mlp_.stagger = env_int("RBL_MLP_STAGGER", 1);
+  mlp_.stagger = env_int("RBL_MLP_STAGGER", 0);
+  for (size_t i = 0; i < pk.inv_scale.size() && i < 8; ++i) mlp_.inv_scale[i] = pk.inv_scale[i];
   mlp_.tape_chunks = pk.tape_chunks;
   mlp_.l0_chunks = pk.l0_chunks;
   mlp_.k0_steps = pk.k0_steps;

@@ -10,10 +10,11 @@ namespace rbl {
 // Device-resident, MFMA-ready copy of a Net2 (cfvpy/models.py:64-94).  Built by pack_mlp() from torch-layout weights.
 struct MlpDev {
   int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
-  int tile = 0;       // kernel variant: 0 = LDS weight tape (n_hidden 256), 16 = 16x16x4 register streaming, 32 = 32x32x2
+  int tile = 0;       // kernel variant: 2 = f16x2-split LDS tape, 0 = f32 LDS tape (both n_hidden 256), 16 / 32 = f32 register streaming
   const float* tape = nullptr;  // variant 0: the packed weights in consumption order, 32 KiB chunks
   int tape_chunks = 0, l0_chunks = 0;
-  int stagger = 1;    // static wave priority by hardware slot parity (see stagger_priority)
+  float inv_scale[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // variant 2: 1 / (power-of-two weight scale) per layer (last = output)
+  int stagger = 0;    // static wave priority by hardware slot parity (see stagger_priority)
   int k0_steps = 0;   // layer-0 k-pairs, padded to a multiple of 4
   int out_tiles = 0;  // ceil(n_out / 32)
   float ln_eps = 1e-5f;
@@ -32,6 +33,7 @@ struct MlpPacked {
   size_t off_w0, off_wh, off_wo, off_bias, off_lnw, off_lnb, off_bout;
   int k0_steps, out_tiles, tile;
   int tape_chunks = 0, l0_chunks = 0;
+  std::vector<float> inv_scale;
 };
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,

@@ -537,6 +537,169 @@ __global__ void __launch_bounds__(256, 2) mlp_tape_forward_kernel(const MlpDev m
   }
 }
 
+
+// ================================================================================================ fp16 x 2-split tape variant
+// f32-input MFMA executes on the SIMD's f32 FMA lanes (64 FLOP/clk/SIMD, the VALU rate), so with it the GEMM time and
+// the LayerNorm/GELU VALU time ADD.  The f16 matrix pipe is 16x faster and separate.  To use it without giving up
+// f32-class accuracy every operand is split into two f16 numbers, v = v_h + 2^-11 v_l (v_h = f16(v), v_l =
+// f16((v - v_h) * 2^11): 22 significant bits, no subnormals thanks to the 2^11 rescale and a per-layer power-of-two
+// weight scale S), and each product is evaluated as three MFMAs accumulated in f32:
+//       acc1 += W_h x_h          acc2 += W_l x_h + W_h x_l          y = (acc1 + 2^-11 acc2) / S
+// (f16 x f16 products are exact in f32; the dropped W_l x_l term is 2^-22 relative).  3/16 of the f32-MFMA cost.
+// Measured max |error| vs float64 on O(1) outputs: ~1e-6 (tests/test_net_parity.py; bar 1e-5).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+union Frag16 {
+  f32x4 v;
+  f16x8 h;
+};
+
+// two f32 -> (hi, lo) f16 pairs.  RTZ on hi is fine: lo carries the remainder.
+__device__ __forceinline__ void split2(float a, float b, f16x2* hi, f16x2* lo) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+  const float ra = (a - (float)h[0]) * 2048.0f, rb = (b - (float)h[1]) * 2048.0f;
+  *hi = h;
+  *lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
+__device__ __forceinline__ void split_tiles(const f32x4& t0, const f32x4& t1, f16x8* hi, f16x8* lo) {
+  f16x2 h[4], l[4];
+  split2(t0[0], t0[1], &h[0], &l[0]);
+  split2(t0[2], t0[3], &h[1], &l[1]);
+  split2(t1[0], t1[1], &h[2], &l[2]);
+  split2(t1[2], t1[3], &h[3], &l[3]);
+  *hi = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+  *lo = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+}
+
+template <int OT>
+__global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev m, const float* __restrict__ queries,
+                                                                   int64_t rows, float* __restrict__ out) {
+  constexpr int NT = 16, KS = 8;  // 16 feature tiles of 16; 8 k-steps of 32 over the hidden width
+  __shared__ f32x4 ring[2 * kChunkF4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
+  const bool valid = row < rows;
+  const float* qrow = queries + (valid ? row : 0) * m.n_in;
+  const f32x4* tape = reinterpret_cast<const f32x4*>(m.tape);
+  const int nchunks = m.tape_chunks;
+
+  auto issue = [&](int c) {
+    if (c < nchunks) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int off = (wave * 8 + i) * 64;
+        __builtin_amdgcn_global_load_lds(tape + (size_t)c * kChunkF4 + off + lane, &ring[(c & 1) * kChunkF4 + off], 16, 0,
+                                         0);
+      }
+    }
+  };
+  issue(0);
+  issue(1);
+  int c = 0;
+  constexpr float kLo = 1.0f / 2048.0f;
+
+  f32x4 y[NT];
+  f32x4 acc1[NT], acc2[NT];
+  // ---------------------------------------------------------------- layer 0: one chunk per 32 inputs
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    acc1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc2[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int ks = 0; ks < m.l0_chunks; ++ks, ++c) {
+    float q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * ks + 8 * g + e;
+      q8[e] = (valid && k < m.n_in) ? qrow[k] : 0.f;
+    }
+    f16x2 h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split2(q8[2 * e], q8[2 * e + 1], &h[e], &l[e]);
+    const f16x8 bh = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+    const f16x8 bl = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+    __syncthreads();
+    const f32x4* buf = &ring[(c & 1) * kChunkF4];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      Frag16 wh, wl;
+      wh.v = buf[(it * 2 + 0) * 64 + lane];
+      wl.v = buf[(it * 2 + 1) * 64 + lane];
+      acc2[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl.h, bh, acc2[it], 0, 0, 0);
+      acc1[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, bh, acc1[it], 0, 0, 0);
+      acc2[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, bl, acc2[it], 0, 0, 0);
+    }
+    __syncthreads();
+    issue(c + 2);
+  }
+#pragma unroll
+  for (int it = 0; it < NT; ++it) y[it] = (acc1[it] + acc2[it] * kLo) * m.inv_scale[0];
+  epilogue16<NT>(y, m.bias, m.ln_w, m.ln_b, m.use_ln, m.ln_eps, g);
+
+  f16x8 xh[KS], xl[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) split_tiles(y[2 * ks], y[2 * ks + 1], &xh[ks], &xl[ks]);
+
+  // one chunk = an output-tile pair: [tile 0..1][k-step 0..7][part h,l]
+  auto pair_from_lds = [&](const f32x4* buf, float inv_s, f32x4& o0, f32x4& o1) {
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag16 ah, al, bh, bl;
+      ah.v = buf[((0 * KS + ks) * 2 + 0) * 64 + lane];
+      al.v = buf[((0 * KS + ks) * 2 + 1) * 64 + lane];
+      bh.v = buf[((1 * KS + ks) * 2 + 0) * 64 + lane];
+      bl.v = buf[((1 * KS + ks) * 2 + 1) * 64 + lane];
+      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, xh[ks], a2, 0, 0, 0);
+      b2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl.h, xh[ks], b2, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, xh[ks], a1, 0, 0, 0);
+      b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh.h, xh[ks], b1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, xl[ks], a2, 0, 0, 0);
+      b2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh.h, xl[ks], b2, 0, 0, 0);
+    }
+    o0 = (a1 + a2 * kLo) * inv_s;
+    o1 = (b1 + b2 * kLo) * inv_s;
+  };
+
+  // ---------------------------------------------------------------- hidden layers: 8 chunks each
+  for (int l = 1; l < m.n_layers; ++l) {
+#pragma unroll
+    for (int ip = 0; ip < NT / 2; ++ip, ++c) {
+      __syncthreads();
+      pair_from_lds(&ring[(c & 1) * kChunkF4], m.inv_scale[l], y[2 * ip], y[2 * ip + 1]);
+      __syncthreads();
+      issue(c + 2);
+    }
+    epilogue16<NT>(y, m.bias + l * 16 * NT, m.ln_w + l * 16 * NT, m.ln_b + l * 16 * NT, m.use_ln, m.ln_eps, g);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) split_tiles(y[2 * ks], y[2 * ks + 1], &xh[ks], &xl[ks]);
+  }
+  // ---------------------------------------------------------------- output layer
+  {
+    f32x4 o[2 * ((OT + 1) / 2)];
+#pragma unroll
+    for (int op = 0; op < (OT + 1) / 2; ++op, ++c) {
+      __syncthreads();
+      pair_from_lds(&ring[(c & 1) * kChunkF4], m.inv_scale[m.n_layers], o[2 * op], o[2 * op + 1]);
+      __syncthreads();
+      issue(c + 2);
+    }
+    if (valid) {
+      float* orow = out + row * m.n_out;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ot * 16 + 4 * g + r;
+          if (i < m.n_out) orow[i] = o[ot][r] + m.b_out[i];
+        }
+    }
+  }
+}
+
 }  // namespace
 
 bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out) {
@@ -652,12 +815,98 @@ static MlpPacked pack_mlp_tape(int n_layers, int n_in, int n_hidden, int n_out, 
   return p;
 }
 
+// f16 x 2-split tape (tile = 2): 16-byte units of 8 halves; fragment = 64 lanes x 16 B; chunk = 32 fragments.
+//   layer 0 : per k-step of 32 inputs one chunk   [tile 0..15][part h,l]        k = 32 ks + 8 g + e
+//   hidden  : per output-tile pair one chunk      [tile 0..1][k-step 0..7][h,l] feature = 16 (2 ks + (e>>2)) + 4 g + (e&3)
+//   output  : as hidden, tile count padded to even
+static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
+                                const float* const* b, const float* const* ln_w, const float* const* ln_b,
+                                const float* w_out, const float* b_out) {
+  MlpPacked p;
+  p.tile = 2;
+  const int NT = 16, KS = 8;
+  const int ks0 = (n_in + 31) / 32;
+  p.k0_steps = ks0;
+  p.out_tiles = (n_out + 15) / 16;
+  const int otp = (p.out_tiles + 1) / 2 * 2;
+  const size_t chunk_f = 2048 * 4;  // floats per chunk
+  const size_t n_w0 = (size_t)ks0 * chunk_f;
+  const size_t n_wh = (size_t)(n_layers - 1) * (NT / 2) * chunk_f;
+  const size_t n_wo = (size_t)(otp / 2) * chunk_f;
+  p.off_w0 = 0;
+  p.off_wh = n_w0;
+  p.off_wo = p.off_wh + n_wh;
+  p.off_bias = p.off_wo + n_wo;
+  p.off_lnw = p.off_bias + (size_t)n_layers * n_hidden;
+  p.off_lnb = p.off_lnw + (size_t)n_layers * n_hidden;
+  p.off_bout = p.off_lnb + (size_t)n_layers * n_hidden;
+  p.blob.assign(p.off_bout + (size_t)otp * 16, 0.f);
+  p.l0_chunks = ks0;
+  p.tape_chunks = (int)(p.off_bias / chunk_f);
+  _Float16* tape = reinterpret_cast<_Float16*>(p.blob.data());
+  auto scale_of = [](const float* W, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(W[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    return std::ldexp(1.0f, (int)std::floor(std::log2(8192.0f / mx)));
+  };
+  // writes fragment `frag` (index in 64-lane x 8-half units from the tape start): rows i0..i0+15, k given by kfun(g, e)
+  auto put = [&](size_t frag, const float* W, int ld, int n_rows, int n_cols, int i0, float S, int part, auto kfun) {
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int i = i0 + (lane & 15), k = kfun(lane >> 4, e);
+        const float v = (i < n_rows && k < n_cols) ? W[(size_t)i * ld + k] * S : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        tape[(frag * 64 + lane) * 8 + e] = part == 0 ? hi : lo;
+      }
+  };
+  p.inv_scale.assign(n_layers + 1, 1.f);
+  {
+    const float S = scale_of(w[0], (size_t)n_hidden * n_in);
+    p.inv_scale[0] = 1.0f / S;
+    for (int ks = 0; ks < ks0; ++ks)
+      for (int it = 0; it < NT; ++it)
+        for (int part = 0; part < 2; ++part)
+          put((size_t)ks * 32 + it * 2 + part, w[0], n_in, n_hidden, n_in, it * 16, S, part,
+              [ks](int g, int e) { return 32 * ks + 8 * g + e; });
+  }
+  auto pack_dense = [&](size_t chunk0, const float* W, int n_rows, int n_pairs, float S) {
+    for (int ip = 0; ip < n_pairs; ++ip)
+      for (int tt = 0; tt < 2; ++tt)
+        for (int ks = 0; ks < KS; ++ks)
+          for (int part = 0; part < 2; ++part)
+            put((chunk0 + ip) * 32 + (tt * KS + ks) * 2 + part, W, n_hidden, n_rows, n_hidden, (2 * ip + tt) * 16, S, part,
+                [ks](int g, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3); });
+  };
+  for (int l = 1; l < n_layers; ++l) {
+    const float S = scale_of(w[l], (size_t)n_hidden * n_hidden);
+    p.inv_scale[l] = 1.0f / S;
+    pack_dense(ks0 + (size_t)(l - 1) * (NT / 2), w[l], n_hidden, NT / 2, S);
+  }
+  {
+    const float S = scale_of(w_out, (size_t)n_out * n_hidden);
+    p.inv_scale[n_layers] = 1.0f / S;
+    pack_dense(ks0 + (size_t)(n_layers - 1) * (NT / 2), w_out, n_out, otp / 2, S);
+  }
+  for (int l = 0; l < n_layers; ++l)
+    for (int i = 0; i < n_hidden; ++i) {
+      p.blob[p.off_bias + (size_t)l * n_hidden + i] = b[l][i];
+      p.blob[p.off_lnw + (size_t)l * n_hidden + i] = use_ln ? ln_w[l][i] : 1.f;
+      p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? ln_b[l][i] : 0.f;
+    }
+  for (int i = 0; i < n_out; ++i) p.blob[p.off_bout + i] = b_out[i];
+  return p;
+}
+
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error("value net shape not supported by the MFMA forward (n_hidden in {64,128,256}, n_out <= 64)");
-  if (tile == 0 && n_hidden == 256 && n_out <= 64)
+  if (tile == 2 && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
+    return pack_mlp_f16x2(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
+  if ((tile == 0 || tile == 2) && n_hidden == 256 && n_out <= 64)
     return pack_mlp_tape(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   if (tile != 32) return pack_mlp16(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   MlpPacked p;
@@ -737,6 +986,17 @@ static void launch_mlp16(const MlpDev& m, const float* queries, int64_t rows, fl
 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
   if (rows <= 0) return;
+  if (m.tile == 2) {
+    const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
+    switch (m.out_tiles) {
+      case 1: hipLaunchKernelGGL(mlp_f16x2_forward_kernel<1>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 2: hipLaunchKernelGGL(mlp_f16x2_forward_kernel<2>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 3: hipLaunchKernelGGL(mlp_f16x2_forward_kernel<3>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 4: hipLaunchKernelGGL(mlp_f16x2_forward_kernel<4>, grid, block, 0, stream, m, queries, rows, out); break;
+      default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+    }
+    return;
+  }
   if (m.tile == 0) {
     const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
     switch (m.out_tiles) {
