@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <stdexcept>
+#include <type_traits>
 
 namespace rbl {
 
@@ -573,11 +574,20 @@ __device__ __forceinline__ void split_tiles(const f32x4& t0, const f32x4& t1, f1
   *lo = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
 }
 
+// Weight tape through LDS, f16x2 variant: 4-slot ring of 16 KiB chunks (one output tile = 8 k-steps x {h,l} fragments),
+// filled by global_load_lds_dwordx4 three chunks ahead.  One raw s_barrier per chunk: at iteration c every wave first
+// retires its own DMA pieces of chunk c+1 (counted s_waitcnt vmcnt, chunk c+2 stays in flight), the barrier then makes
+// chunk c+1 visible to all waves AND proves that everybody is done with chunk c-1, whose slot is refilled with chunk c+3
+// right away.  Because chunk c+1 is already visible while chunk c is being multiplied, the LDS->register fragment ring
+// (PF k-steps ahead, pinned with sched_barrier) runs straight across chunk boundaries.
+constexpr int kSlotF4 = 1024;  // f32x4 (16-byte) units per 16 KiB ring slot
+constexpr int kSlots = 4;
+
 template <int OT>
 __global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                    int64_t rows, float* __restrict__ out) {
-  constexpr int NT = 16, KS = 8;  // 16 feature tiles of 16; 8 k-steps of 32 over the hidden width
-  __shared__ f32x4 ring[2 * kChunkF4];
+  constexpr int NT = 16, KS = 8, PF = 3;
+  __shared__ f32x4 ring[kSlots * kSlotF4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
@@ -586,107 +596,142 @@ __global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev 
   const f32x4* tape = reinterpret_cast<const f32x4*>(m.tape);
   const int nchunks = m.tape_chunks;
 
-  auto issue = [&](int c) {
+  auto issue = [&](int c) {  // each wave moves 4 KiB of the chunk: 4 wave-instructions of 1 KiB
     if (c < nchunks) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int off = (wave * 8 + i) * 64;
-        __builtin_amdgcn_global_load_lds(tape + (size_t)c * kChunkF4 + off + lane, &ring[(c & 1) * kChunkF4 + off], 16, 0,
-                                         0);
+      for (int i = 0; i < 4; ++i) {
+        const int off = (wave * 4 + i) * 64;
+        __builtin_amdgcn_global_load_lds(tape + (size_t)c * kSlotF4 + off + lane,
+                                         &ring[(c & (kSlots - 1)) * kSlotF4 + off], 16, 0, 0);
       }
     }
   };
+  // ring cursors: per-lane pointers to the slot of the current chunk and of the next one (updated once per chunk, so
+  // every fragment address below is cursor + compile-time offset)
+  int slot = 0;
+  const f32x4* pcur = &ring[lane];
+  const f32x4* pnxt = &ring[kSlotF4 + lane];
+  bool first_turn = true;
+  // start of iteration c: chunk c+1 landed everywhere, slot of chunk c-1 free -> refill it with chunk c+3
+  auto turn = [&](int c) {
+    if (c + 2 < nchunks)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(c + 3);
+    if (!first_turn) {
+      slot = (slot + 1) & (kSlots - 1);
+      pcur = pnxt;
+      pnxt = &ring[((slot + 1) & (kSlots - 1)) * kSlotF4 + lane];
+    }
+    first_turn = false;
+  };
+  auto frag = [&](const f32x4* cursor, int idx) -> f16x8 {
+    Frag16 f;
+    f.v = cursor[idx * 64];
+    return f.h;
+  };
   issue(0);
   issue(1);
+  issue(2);
   int c = 0;
   constexpr float kLo = 1.0f / 2048.0f;
 
   f32x4 y[NT];
-  f32x4 acc1[NT], acc2[NT];
-  // ---------------------------------------------------------------- layer 0: one chunk per 32 inputs
-#pragma unroll
-  for (int it = 0; it < NT; ++it) {
-    acc1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc2[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  for (int ks = 0; ks < m.l0_chunks; ++ks, ++c) {
-    float q8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 32 * ks + 8 * g + e;
-      q8[e] = (valid && k < m.n_in) ? qrow[k] : 0.f;
-    }
-    f16x2 h[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) split2(q8[2 * e], q8[2 * e + 1], &h[e], &l[e]);
-    const f16x8 bh = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
-    const f16x8 bl = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
-    __syncthreads();
-    const f32x4* buf = &ring[(c & 1) * kChunkF4];
+  {  // ---------------------------------------------------------------- layer 0: two chunks (8 tiles each) per 32 inputs
+    f32x4 acc1[NT], acc2[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-      Frag16 wh, wl;
-      wh.v = buf[(it * 2 + 0) * 64 + lane];
-      wl.v = buf[(it * 2 + 1) * 64 + lane];
-      acc2[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl.h, bh, acc2[it], 0, 0, 0);
-      acc1[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, bh, acc1[it], 0, 0, 0);
-      acc2[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, bl, acc2[it], 0, 0, 0);
+      acc1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc2[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    issue(c + 2);
-  }
+    for (int ks = 0; ks < m.l0_chunks; ++ks) {
+      float q8[8];
 #pragma unroll
-  for (int it = 0; it < NT; ++it) y[it] = (acc1[it] + acc2[it] * kLo) * m.inv_scale[0];
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * g + e;
+        q8[e] = (valid && k < m.n_in) ? qrow[k] : 0.f;
+      }
+      f16x2 h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split2(q8[2 * e], q8[2 * e + 1], &h[e], &l[e]);
+      const f16x8 bh = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+      const f16x8 bl = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+#pragma unroll
+      for (int half = 0; half < 2; ++half, ++c) {
+        turn(c);
+        f16x8 wh[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          wh[t] = frag(pcur, t * 2 + 0);
+          const f16x8 wl = frag(pcur, t * 2 + 1);
+          acc2[half * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc2[half * 8 + t], 0, 0, 0);
+          acc1[half * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, acc1[half * 8 + t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc2[half * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, acc2[half * 8 + t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) y[it] = (acc1[it] + acc2[it] * kLo) * m.inv_scale[0];
+  }
   epilogue16<NT>(y, m.bias, m.ln_w, m.ln_b, m.use_ln, m.ln_eps, g);
 
   f16x8 xh[KS], xl[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) split_tiles(y[2 * ks], y[2 * ks + 1], &xh[ks], &xl[ks]);
 
-  // one chunk = an output-tile pair: [tile 0..1][k-step 0..7][part h,l]
-  auto pair_from_lds = [&](const f32x4* buf, float inv_s, f32x4& o0, f32x4& o1) {
-    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, b1 = a1, b2 = a1;
+  // TILES output tiles = TILES chunks, one long k-step stream: step t = (tile t / KS, k-step t % KS)
+  auto dense = [&](auto tiles_tag, float inv_s, auto& dst) {
+    constexpr int TILES = decltype(tiles_tag)::value;
+    constexpr int T = TILES * KS;
+    f16x8 rh[PF], rl[PF];
+    turn(c);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag16 ah, al, bh, bl;
-      ah.v = buf[((0 * KS + ks) * 2 + 0) * 64 + lane];
-      al.v = buf[((0 * KS + ks) * 2 + 1) * 64 + lane];
-      bh.v = buf[((1 * KS + ks) * 2 + 0) * 64 + lane];
-      bl.v = buf[((1 * KS + ks) * 2 + 1) * 64 + lane];
-      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al.h, xh[ks], a2, 0, 0, 0);
-      b2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl.h, xh[ks], b2, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, xh[ks], a1, 0, 0, 0);
-      b1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh.h, xh[ks], b1, 0, 0, 0);
-      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah.h, xl[ks], a2, 0, 0, 0);
-      b2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh.h, xl[ks], b2, 0, 0, 0);
+    for (int t = 0; t < PF; ++t) {
+      rh[t] = frag(pcur, t * 2 + 0);
+      rl[t] = frag(pcur, t * 2 + 1);
     }
-    o0 = (a1 + a2 * kLo) * inv_s;
-    o1 = (b1 + b2 * kLo) * inv_s;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+#pragma unroll
+    for (int tile = 0; tile < TILES; ++tile) {
+      if (tile > 0) turn(c + tile);  // chunk c+tile+1 becomes visible before we prefetch into it
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int t = tile * KS + ks, rs = t % PF;
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[rs], xh[ks], a2, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[rs], xh[ks], a1, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[rs], xl[ks], a3, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + PF < T) {
+          const int u = t + PF;
+          const f32x4* cursor = (u / KS == tile) ? pcur : pnxt;  // chunk of step u: this one or the next (visible)
+          rh[rs] = frag(cursor, (u % KS) * 2 + 0);
+          rl[rs] = frag(cursor, (u % KS) * 2 + 1);
+        }
+      }
+      dst[tile] = (a1 + (a2 + a3) * kLo) * inv_s;
+      a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      a2 = a1;
+      a3 = a1;
+    }
+    c += TILES;
   };
 
-  // ---------------------------------------------------------------- hidden layers: 8 chunks each
+  // ---------------------------------------------------------------- hidden layers: 16 chunks each
   for (int l = 1; l < m.n_layers; ++l) {
-#pragma unroll
-    for (int ip = 0; ip < NT / 2; ++ip, ++c) {
-      __syncthreads();
-      pair_from_lds(&ring[(c & 1) * kChunkF4], m.inv_scale[l], y[2 * ip], y[2 * ip + 1]);
-      __syncthreads();
-      issue(c + 2);
-    }
+    dense(std::integral_constant<int, NT>{}, m.inv_scale[l], y);
     epilogue16<NT>(y, m.bias + l * 16 * NT, m.ln_w + l * 16 * NT, m.ln_b + l * 16 * NT, m.use_ln, m.ln_eps, g);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) split_tiles(y[2 * ks], y[2 * ks + 1], &xh[ks], &xl[ks]);
   }
-  // ---------------------------------------------------------------- output layer
+  // ---------------------------------------------------------------- output layer: OT chunks
   {
-    f32x4 o[2 * ((OT + 1) / 2)];
-#pragma unroll
-    for (int op = 0; op < (OT + 1) / 2; ++op, ++c) {
-      __syncthreads();
-      pair_from_lds(&ring[(c & 1) * kChunkF4], m.inv_scale[m.n_layers], o[2 * op], o[2 * op + 1]);
-      __syncthreads();
-      issue(c + 2);
-    }
+    f32x4 o[OT];
+    dense(std::integral_constant<int, OT>{}, m.inv_scale[m.n_layers], o);
     if (valid) {
       float* orow = out + row * m.n_out;
 #pragma unroll
@@ -815,10 +860,10 @@ static MlpPacked pack_mlp_tape(int n_layers, int n_in, int n_hidden, int n_out, 
   return p;
 }
 
-// f16 x 2-split tape (tile = 2): 16-byte units of 8 halves; fragment = 64 lanes x 16 B; chunk = 32 fragments.
-//   layer 0 : per k-step of 32 inputs one chunk   [tile 0..15][part h,l]        k = 32 ks + 8 g + e
-//   hidden  : per output-tile pair one chunk      [tile 0..1][k-step 0..7][h,l] feature = 16 (2 ks + (e>>2)) + 4 g + (e&3)
-//   output  : as hidden, tile count padded to even
+// f16 x 2-split tape (tile = 2): 16-byte units of 8 halves; fragment = 64 lanes x 16 B; chunk = 16 fragments (16 KiB).
+//   layer 0 : per k-step of 32 inputs two chunks  [tile 0..7][part h,l]        k = 32 ks + 8 g + e
+//   hidden  : per output tile one chunk           [k-step 0..7][part h,l]      feature = 16 (2 ks + (e>>2)) + 4 g + (e&3)
+//   output  : as hidden
 static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                                 const float* const* b, const float* const* ln_w, const float* const* ln_b,
                                 const float* w_out, const float* b_out) {
@@ -828,11 +873,10 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
   const int ks0 = (n_in + 31) / 32;
   p.k0_steps = ks0;
   p.out_tiles = (n_out + 15) / 16;
-  const int otp = (p.out_tiles + 1) / 2 * 2;
-  const size_t chunk_f = 2048 * 4;  // floats per chunk
-  const size_t n_w0 = (size_t)ks0 * chunk_f;
-  const size_t n_wh = (size_t)(n_layers - 1) * (NT / 2) * chunk_f;
-  const size_t n_wo = (size_t)(otp / 2) * chunk_f;
+  const size_t chunk_f = 1024 * 4;  // floats per 16 KiB chunk
+  const size_t n_w0 = (size_t)ks0 * 2 * chunk_f;
+  const size_t n_wh = (size_t)(n_layers - 1) * NT * chunk_f;
+  const size_t n_wo = (size_t)p.out_tiles * chunk_f;
   p.off_w0 = 0;
   p.off_wh = n_w0;
   p.off_wo = p.off_wh + n_wh;
@@ -840,7 +884,7 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
   p.off_lnw = p.off_bias + (size_t)n_layers * n_hidden;
   p.off_lnb = p.off_lnw + (size_t)n_layers * n_hidden;
   p.off_bout = p.off_lnb + (size_t)n_layers * n_hidden;
-  p.blob.assign(p.off_bout + (size_t)otp * 16, 0.f);
+  p.blob.assign(p.off_bout + (size_t)p.out_tiles * 16, 0.f);
   p.l0_chunks = ks0;
   p.tape_chunks = (int)(p.off_bias / chunk_f);
   _Float16* tape = reinterpret_cast<_Float16*>(p.blob.data());
@@ -868,26 +912,25 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
     for (int ks = 0; ks < ks0; ++ks)
       for (int it = 0; it < NT; ++it)
         for (int part = 0; part < 2; ++part)
-          put((size_t)ks * 32 + it * 2 + part, w[0], n_in, n_hidden, n_in, it * 16, S, part,
+          put(((size_t)ks * 2 + it / 8) * 16 + (it % 8) * 2 + part, w[0], n_in, n_hidden, n_in, it * 16, S, part,
               [ks](int g, int e) { return 32 * ks + 8 * g + e; });
   }
-  auto pack_dense = [&](size_t chunk0, const float* W, int n_rows, int n_pairs, float S) {
-    for (int ip = 0; ip < n_pairs; ++ip)
-      for (int tt = 0; tt < 2; ++tt)
-        for (int ks = 0; ks < KS; ++ks)
-          for (int part = 0; part < 2; ++part)
-            put((chunk0 + ip) * 32 + (tt * KS + ks) * 2 + part, W, n_hidden, n_rows, n_hidden, (2 * ip + tt) * 16, S, part,
-                [ks](int g, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3); });
+  auto pack_dense = [&](size_t chunk0, const float* W, int n_rows, int n_tiles, float S) {
+    for (int it = 0; it < n_tiles; ++it)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int part = 0; part < 2; ++part)
+          put((chunk0 + it) * 16 + ks * 2 + part, W, n_hidden, n_rows, n_hidden, it * 16, S, part,
+              [ks](int g, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * g + (e & 3); });
   };
   for (int l = 1; l < n_layers; ++l) {
     const float S = scale_of(w[l], (size_t)n_hidden * n_hidden);
     p.inv_scale[l] = 1.0f / S;
-    pack_dense(ks0 + (size_t)(l - 1) * (NT / 2), w[l], n_hidden, NT / 2, S);
+    pack_dense((size_t)ks0 * 2 + (size_t)(l - 1) * NT, w[l], n_hidden, NT, S);
   }
   {
     const float S = scale_of(w_out, (size_t)n_out * n_hidden);
     p.inv_scale[n_layers] = 1.0f / S;
-    pack_dense(ks0 + (size_t)(n_layers - 1) * (NT / 2), w_out, n_out, otp / 2, S);
+    pack_dense((size_t)ks0 * 2 + (size_t)(n_layers - 1) * NT, w_out, n_out, p.out_tiles, S);
   }
   for (int l = 0; l < n_layers; ++l)
     for (int i = 0; i < n_hidden; ++i) {
