@@ -51,12 +51,16 @@ struct CfrArgs {
   int mode, trav, next_trav, steps_after;
   double alpha;            // root-mean step size (subgame_solving.cc:580-590)
   double pos, neg, strat;  // discounts (:592-617)
+  long long* dbg;          // optional [B][16] phase timestamps (s_memtime) written by thread 0; null in production
 };
 
-// reals of per-lane working set: rho0, rho1, val [N][H], sigma [E][H], tmp
-inline size_t cfr_work_reals(int N, int H, int L, int T, int dice) {
+// reals (8-byte units) of the per-lane working set: rho0, rho1, val [N][H], sigma and regrets [E][H], tmp, leaf values
+// [L][H] f32, the lane's tree tables (5N + L + T ints) and the match table (faces x H bytes)
+inline size_t cfr_work_reals(int N, int H, int L, int T, int dice, int faces) {
   const size_t tmp = (size_t)std::max(2 * L, L + T * (2 * dice + 2)) + 2;
-  return (size_t)3 * N * H + (size_t)(N - 1) * H + tmp;
+  const size_t lv = ((size_t)L * H + 1) / 2 + 1;
+  const size_t tabs = ((size_t)(5 * N + L + T) * 4 + (size_t)faces * H + 7) / 8 + 1;
+  return (size_t)3 * N * H + (size_t)2 * (N - 1) * H + tmp + lv + tabs;
 }
 
 // test double of the value net (oracle/orc_api.h: orc_synthetic_net); lives in the -ffp-contract=off TU

@@ -34,17 +34,42 @@ struct LaneView {
   const int* terms;
 };
 
-// Reach of `player` under sigma, top-down by BFS level (compute_reach_probabilities, subgame_solving.cc:54-78).
-// rho[0] must hold the root beliefs.  Level d reads level d-1 only, so one barrier per level.
-__device__ __forceinline__ void sweep_reach(const LaneView& v, const double* sig, double* rho, int player,
-                                            int root_player, int H) {
+// Loops over (node, hand) / (row, column) pairs are division-free: a thread fixes its column (hand) once and strides
+// over rows; threads beyond rows_per_pass * width idle (2 of 128 for H = 6).
+struct Grid2 {
+  int col, row0, rpp;  // this thread's column, first row, rows per pass
+  bool active;
+  __device__ Grid2(int width) {
+    rpp = blockDim.x / width;
+    if (rpp < 1) rpp = 1;
+    col = threadIdx.x % width;
+    row0 = threadIdx.x / width;
+    active = (int)threadIdx.x < rpp * width;
+  }
+};
+
+// Reach of BOTH players under sigma, top-down by BFS level (compute_reach_probabilities, subgame_solving.cc:54-78).
+// rho*[0] must hold the root beliefs.  Level d reads level d-1 only, so one barrier per level.  `only` >= 0 restricts
+// the sweep to that player (the traverser's reach under the new sigma, :636-638).
+__device__ __forceinline__ void sweep_reach(const LaneView& v, const double* sig, double* rho0, double* rho1, int only,
+                                            int root_player, int H, const Grid2& gh) {
   for (int lev = 1; lev < v.nlev; ++lev) {
-    const int n0 = v.lev_off[lev], cnt = (v.lev_off[lev + 1] - n0) * H;
-    const bool own = ((root_player ^ ((lev - 1) & 1)) == player);  // mover of the parents of this level
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-      const int n = n0 + i / H, h = i % H;
-      const double up = rho[v.parent[n] * H + h];
-      rho[n * H + h] = own ? up * sig[(n - 1) * H + h] : up;
+    const int n0 = v.lev_off[lev], n1 = v.lev_off[lev + 1];
+    const int mover = root_player ^ ((lev - 1) & 1);  // mover of the parents of this level
+    if (gh.active && gh.row0 < n1 - n0) {
+      const int h = gh.col;
+      for (int n = n0 + gh.row0; n < n1; n += gh.rpp) {
+        const int p = v.parent[n] * H + h;
+        const double s = sig[(n - 1) * H + h];
+        if (only != 1) {
+          const double up = rho0[p];
+          rho0[n * H + h] = mover == 0 ? up * s : up;
+        }
+        if (only != 0) {
+          const double up = rho1[p];
+          rho1[n * H + h] = mover == 1 ? up * s : up;
+        }
+      }
     }
     __syncthreads();
   }
@@ -72,6 +97,15 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
   const int root_player = a.lane_root_player[lane];
   const int row_off = a.lane_row_off[lane];
   const int nbins = 2 * a.dice + 1;
+  const Grid2 gh(H);
+  long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
+  int dbg_k = 0;
+#define RBL_STAMP()                                                    \
+  do {                                                                 \
+    if (dbg && threadIdx.x == 0) dbg[dbg_k] = (long long)clock64();    \
+    ++dbg_k;                                                           \
+  } while (0)
+  RBL_STAMP();  // 0: start
 
   // working set: LDS when it fits, else a per-lane slab of global scratch (big trees: 2 dice x 6 faces, full trees)
   double* W = a.use_lds ? lds : a.scratch + (size_t)lane * a.work_stride;
@@ -79,8 +113,11 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
   double* rho1 = rho0 + NH;
   double* val = rho1 + NH;
   double* sig = val + NH;
-  double* tmp = sig + EH;
-
+  double* reg = sig + EH;  // regrets staged like sigma: all irregular access happens here, global traffic is flat
+  double* tmp = reg + EH;
+  const int tmp_n = max(2 * v.L, v.L + v.T * (nbins + 1)) + 2;
+  float* lvals = reinterpret_cast<float*>(tmp + tmp_n);  // [L][H] leaf values of the pending queries
+  const int8_t* mtab = a.matches;
   const size_t lane_e = (size_t)lane * a.Emax * H;
   double* g_sig = a.sigma + lane_e;
   double* g_reg = a.regrets + lane_e;
@@ -88,44 +125,84 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
   const double* bel = a.beliefs + (size_t)lane * 2 * H;
   double* rmean = a.root_mean + (size_t)lane * 2 * H;
 
-  // ---------------------------------------------------------------- stage sigma (or build the uniform one)
+  // ---------------------------------------------------------------- stage everything the lane touches, in ONE sweep
+  // (all loads of an iteration are in flight together): sigma, regrets, the leaf values of the pending queries, and --
+  // LDS mode only -- the lane's tree tables and the match table.  Every phase below is a chain of dependent look-ups;
+  // an L2 round trip per look-up, times ~10 phases, is what a lane's latency used to be made of.
+  {
+    int* it = reinterpret_cast<int*>(lvals + ((v.L * H + 1) & ~1));
+    int* t_parent = it, *t_act = it + N, *t_cb = it + 2 * N, *t_ce = it + 3 * N, *t_depth = it + 4 * N;
+    int* t_leaves = it + 5 * N, *t_terms = t_leaves + v.L;
+    int8_t* t_match = reinterpret_cast<int8_t*>(t_terms + v.T);
+    const bool step = a.mode == kModeStep, load_sig = a.mode != kModeInit;
+    const float* gv = a.values + (size_t)row_off * H;
+    const int n_lv = (step && a.use_lds) ? v.L * H : 0, n_mt = a.use_lds ? a.faces * H : 0, n_tab = a.use_lds ? N : 0;
+    const int n_all = max(max(load_sig ? EH : 0, n_tab), max(n_lv, n_mt));
+    for (int i = threadIdx.x; i < n_all; i += blockDim.x) {
+      if (load_sig && i < EH) {
+        sig[i] = g_sig[i];
+        if (step) reg[i] = g_reg[i];
+      }
+      if (i < n_lv) lvals[i] = gv[i];
+      if (i < n_tab) {
+        t_parent[i] = v.parent[i];
+        t_act[i] = v.act[i];
+        t_cb[i] = v.cb[i];
+        t_ce[i] = v.ce[i];
+        t_depth[i] = v.depth[i];
+        if (i < v.L) t_leaves[i] = v.leaves[i];
+        if (i < v.T) t_terms[i] = v.terms[i];
+      }
+      if (i < n_mt) t_match[i] = a.matches[i];
+    }
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+      rho0[i] = bel[i];
+      rho1[i] = bel[H + i];
+    }
+    __syncthreads();
+    if (a.use_lds) {
+      v.parent = t_parent;
+      v.act = t_act;
+      v.cb = t_cb;
+      v.ce = t_ce;
+      v.depth = t_depth;
+      v.leaves = t_leaves;
+      v.terms = t_terms;
+      mtab = t_match;
+    }
+  }
+
   if (a.mode == kModeInit) {
     // get_uniform_strategy (subgame_solving.cc:718-730): 1/#children on the edges out of every internal node
-    for (int i = threadIdx.x; i < EH; i += blockDim.x) {
-      const int n = 1 + i / H;
-      const int p = v.parent[n];
-      const double u = 1. / (v.ce[p] - v.cb[p]);
-      sig[i] = u;
-      g_sig[i] = u;
-      g_reg[i] = 0.0;
-    }
+    if (gh.active)
+      for (int n = 1 + gh.row0; n < N; n += gh.rpp) {
+        const int p = v.parent[n], i = (n - 1) * H + gh.col;
+        const double u = 1. / (v.ce[p] - v.cb[p]);
+        sig[i] = u;
+        g_sig[i] = u;
+        g_reg[i] = 0.0;
+      }
     for (int i = threadIdx.x; i < 2 * H; i += blockDim.x) rmean[i] = 0.0;
-  } else {
-    for (int i = threadIdx.x; i < EH; i += blockDim.x) sig[i] = g_sig[i];
+    __syncthreads();
   }
-  for (int i = threadIdx.x; i < H; i += blockDim.x) {
-    rho0[i] = bel[i];
-    rho1[i] = bel[H + i];
-  }
-  __syncthreads();
+  RBL_STAMP();  // 1: staged
 
   // ---------------------------------------------------------------- reach of both players under sigma (:539)
-  sweep_reach(v, sig, rho0, 0, root_player, H);
-  sweep_reach(v, sig, rho1, 1, root_player, H);
+  sweep_reach(v, sig, rho0, rho1, -1, root_player, H, gh);
+  RBL_STAMP();  // 2: reach
 
   if (a.mode == kModeInit) {
     // sum_strategies = uniform * own reach on the mover's nodes (get_uniform_reach_weigted_strategy, :125-149)
-    for (int i = threadIdx.x; i < EH; i += blockDim.x) {
-      const int n = 1 + i / H, h = i % H;
-      const int p = v.parent[n];
-      const int mover = root_player ^ (v.depth[p] & 1);
-      const double r = (mover == 0 ? rho0 : rho1)[p * H + h];
-      g_sum[i] = sig[i] * r;
-    }
-    if (a.lane_act_iter && a.lane_act_iter[lane] == 0) {
-      double* snap = a.snapshot + lane_e;
-      for (int i = threadIdx.x; i < EH; i += blockDim.x) snap[i] = sig[i];
-    }
+    const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == 0;
+    double* snap = a.snapshot + lane_e;
+    if (gh.active)
+      for (int n = 1 + gh.row0; n < N; n += gh.rpp) {
+        const int p = v.parent[n], h = gh.col, i = (n - 1) * H + h;
+        const int mover = root_player ^ (v.depth[p] & 1);
+        const double r = (mover == 0 ? rho0 : rho1)[p * H + h];
+        g_sum[i] = sig[i] * r;
+        if (snap_now) snap[i] = sig[i];
+      }
   }
 
   if (a.mode == kModeStep) {
@@ -146,7 +223,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
         const int zi = i - v.L, z = v.terms[zi];
         const int bid = v.act[v.parent[z]];
         const int face = bid % a.faces;
-        const int8_t* m = a.matches + face * H;
+        const int8_t* m = mtab + face * H;
         const double* r = rho_o + z * H;
         double* b = tbins + zi * (nbins + 1);
         for (int k = 0; k < nbins; ++k) b[k] = 0.0;
@@ -160,63 +237,71 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       }
     }
     __syncthreads();
+    RBL_STAMP();  // 3: leaf scalers
 
     // -------------------------------------------------------------- leaf and terminal values for the traverser
-    for (int i = threadIdx.x; i < (v.L + v.T) * H; i += blockDim.x) {
-      const int k = i / H, h = i % H;
-      if (k < v.L) {  // leaf_values(float) *= scalers(double), stored back as float (:268), read as double (:275)
-        const float x = a.values[(size_t)(row_off + k) * H + h];
-        val[v.leaves[k] * H + h] = (double)(float)((double)x * lscale[k]);
-      } else {  // compute_expected_terminal_values (:80-98)
-        const int zi = k - v.L, z = v.terms[zi];
-        const int bid = v.act[v.parent[z]];
-        const int qty = 1 + bid / a.faces, face = bid % a.faces;
-        const double* b = tbins + zi * (nbins + 1);
-        const int left = max(0, qty - (int)a.matches[face * H + h]);
-        const float pwin = (float)b[left];  // fp32 truncation (:785)
-        double x = (double)pwin * 2 - b[nbins];
-        // mover(z) is the player who did NOT call liar; inverse when that is not the traverser (:88-95)
-        if ((root_player ^ (v.depth[z] & 1)) != t) x *= -1.0;
-        val[z * H + h] = x;
+    if (gh.active) {
+      const int h = gh.col;
+      for (int k = gh.row0; k < v.L + v.T; k += gh.rpp) {
+        if (k < v.L) {  // leaf_values(float) *= scalers(double), stored back as float (:268), read as double (:275)
+          const float x = a.use_lds ? lvals[k * H + h] : a.values[(size_t)(row_off + k) * H + h];
+          val[v.leaves[k] * H + h] = (double)(float)((double)x * lscale[k]);
+        } else {  // compute_expected_terminal_values (:80-98)
+          const int zi = k - v.L, z = v.terms[zi];
+          const int bid = v.act[v.parent[z]];
+          const int qty = 1 + bid / a.faces, face = bid % a.faces;
+          const double* b = tbins + zi * (nbins + 1);
+          const int left = max(0, qty - (int)mtab[face * H + h]);
+          const float pwin = (float)b[left];  // fp32 truncation (:785)
+          double x = (double)pwin * 2 - b[nbins];
+          // mover(z) is the player who did NOT call liar; inverse when that is not the traverser (:88-95)
+          if ((root_player ^ (v.depth[z] & 1)) != t) x *= -1.0;
+          val[z * H + h] = x;
+        }
       }
     }
     __syncthreads();
+    RBL_STAMP();  // 4: leaf values
 
     // -------------------------------------------------------------- bottom-up sweep (update_regrets, :542-574)
     // fused with regret matching (:619-634) and the regret discount (:639-650) of the same (node, hand) row.
     for (int lev = v.nlev - 2; lev >= 0; --lev) {
-      const int n0 = v.lev_off[lev], cnt = (v.lev_off[lev + 1] - n0) * H;
+      const int n0 = v.lev_off[lev], n1 = v.lev_off[lev + 1];
       const bool mine = ((root_player ^ (lev & 1)) == t);
-      for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const int n = n0 + i / H, h = i % H;
-        const int c0 = v.cb[n], c1 = v.ce[n];
-        if (c0 == c1) continue;
-        double x = 0.0;
-        if (mine) {
-          for (int c = c0; c < c1; ++c) x += val[c * H + h] * sig[(c - 1) * H + h];
-          double s = 0.0;
-          for (int c = c0; c < c1; ++c) {
-            const int e = (c - 1) * H + h;
-            double r = g_reg[e];
-            r += val[c * H + h];
-            r -= x;
-            const double m = r > kEps ? r : kEps;  // std::max(regret, eps)
-            s += m;
-            sig[e] = m;
-            g_reg[e] = r * (r > 0 ? a.pos : a.neg);
+      if (gh.active) {
+        const int h = gh.col;
+        for (int n = n0 + gh.row0; n < n1; n += gh.rpp) {
+          const int c0 = v.cb[n], c1 = v.ce[n];
+          if (c0 == c1) continue;
+          const double* vc = val + c0 * H + h;
+          double x = 0.0;
+          if (mine) {
+            const double* sc = sig + (c0 - 1) * H + h;
+            double* rc = reg + (c0 - 1) * H + h;
+            const int cnt = c1 - c0;
+            for (int k = 0; k < cnt; ++k) x += vc[k * H] * sc[k * H];
+            double s = 0.0;
+            for (int k = 0; k < cnt; ++k) {
+              double r = rc[k * H];
+              r += vc[k * H];
+              r -= x;
+              const double m = r > kEps ? r : kEps;  // std::max(regret, eps)
+              s += m;
+              sig[(c0 - 1 + k) * H + h] = m;
+              rc[k * H] = r * (r > 0 ? a.pos : a.neg);
+            }
+            for (int k = 0; k < cnt; ++k) sig[(c0 - 1 + k) * H + h] = sc[k * H] / s;
+          } else {
+            const int cnt = c1 - c0;
+            for (int k = 0; k < cnt; ++k) x += vc[k * H];
           }
-          for (int c = c0; c < c1; ++c) {
-            const int e = (c - 1) * H + h;
-            sig[e] = sig[e] / s;
-          }
-        } else {
-          for (int c = c0; c < c1; ++c) x += val[c * H + h];
+          val[n * H + h] = x;
         }
-        val[n * H + h] = x;
       }
       __syncthreads();
     }
 
+    RBL_STAMP();  // 5: bottom-up
     // -------------------------------------------------------------- running mean of the root values (:579-590)
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
       double m = rmean[t * H + h];
@@ -225,26 +310,30 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     }
 
     // -------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638)
-    sweep_reach(v, sig, rho_t, t, root_player, H);
+    sweep_reach(v, sig, rho0, rho1, t, root_player, H, gh);
+    RBL_STAMP();  // 6: new reach
 
-    // -------------------------------------------------------------- sum_strategies (:651-657) + write sigma back
-    for (int i = threadIdx.x; i < EH; i += blockDim.x) {
-      const int n = 1 + i / H, h = i % H;
-      const int p = v.parent[n];
-      if ((root_player ^ (v.depth[p] & 1)) == t) {
-        double s = g_sum[i];
-        s *= a.strat;
-        s += rho_t[p * H + h] * sig[i];
-        g_sum[i] = s;
-        g_sig[i] = sig[i];
-      }
-    }
-    if (a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after) {
+    // -------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
+    {
+      const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after;
       double* snap = a.snapshot + lane_e;
-      for (int i = threadIdx.x; i < EH; i += blockDim.x) snap[i] = sig[i];
+      if (gh.active)
+        for (int n = 1 + gh.row0; n < N; n += gh.rpp) {
+          const int p = v.parent[n], h = gh.col, i = (n - 1) * H + h;
+          if ((root_player ^ (v.depth[p] & 1)) == t) {
+            double s = g_sum[i];
+            s *= a.strat;
+            s += rho_t[p * H + h] * sig[i];
+            g_sum[i] = s;
+            g_sig[i] = sig[i];
+            g_reg[i] = reg[i];
+          }
+          if (snap_now) snap[i] = sig[i];
+        }
     }
   }
 
+  RBL_STAMP();  // 7 (3 in init/query modes): write-back
   // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
   if (a.next_trav >= 0 && v.L > 0) {
     double* qsum = tmp;  // [L][2]
@@ -257,24 +346,31 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     }
     __syncthreads();
     float* q = a.queries + (size_t)row_off * Q;
-    for (int i = threadIdx.x; i < v.L * Q; i += blockDim.x) {
-      const int k = i / Q, j = i % Q;
-      const int n = v.leaves[k];
-      float x;
-      if (j == 0) {
-        x = (float)(root_player ^ (v.depth[n] & 1));  // state.player_id
-      } else if (j == 1) {
-        x = (float)a.next_trav;
-      } else if (j < 2 + A) {
-        x = (j - 2 == v.act[n]) ? 1.0f : 0.0f;
-      } else {
-        const int pj = j - 2 - A;
-        const int p = pj >= H, h = pj - p * H;
-        x = (float)(((p ? rho1 : rho0)[n * H + h] + kEps) / qsum[2 * k + p]);
+    const Grid2 gq(Q);
+    if (gq.active) {
+      const int jq = gq.col;
+      // column kind is fixed per thread: 0 = mover flag, 1 = traverser flag, 2 = one-hot of the last bid, 3/4 = beliefs
+      const int pj = jq - 2 - A;
+      const int kind = jq == 0 ? 0 : jq == 1 ? 1 : jq < 2 + A ? 2 : (pj >= H ? 4 : 3);
+      const int hq = kind == 4 ? pj - H : pj;
+      for (int k = gq.row0; k < v.L; k += gq.rpp) {
+        const int n = v.leaves[k];
+        float x;
+        if (kind == 0)
+          x = (float)(root_player ^ (v.depth[n] & 1));  // state.player_id
+        else if (kind == 1)
+          x = (float)a.next_trav;
+        else if (kind == 2)
+          x = (jq - 2 == v.act[n]) ? 1.0f : 0.0f;
+        else
+          x = (float)(((kind == 4 ? rho1 : rho0)[n * H + hq] + kEps) / qsum[2 * k + (kind == 4)]);
+        q[k * Q + jq] = x;
       }
-      q[i] = x;
     }
   }
+  __syncthreads();
+  RBL_STAMP();  // 8: queries
+#undef RBL_STAMP
 }
 
 // Test double of the value net (oracle/orc_api.h: orc_synthetic_net), elementwise, exact in IEEE float:

@@ -78,14 +78,18 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   values_zeroed_ = true;
 
   // working set per lane: LDS if it fits in one CU's 160 KB with room for >= 2 workgroups, else global scratch
-  work_stride_ = cfr_work_reals(nmax_, g_.H, tabs_.max_L, tabs_.max_T, g_.dice);
+  work_stride_ = cfr_work_reals(nmax_, g_.H, tabs_.max_L, tabs_.max_T, g_.dice, g_.faces);
   lds_bytes_ = work_stride_ * sizeof(double);
   const size_t lds_cap = (size_t)env_int("RBL_CFR_LDS_CAP", 80 * 1024);
   use_lds_ = lds_bytes_ <= lds_cap;
   if (!use_lds_) d_scratch_.alloc(L * work_stride_);
   const int nh = nmax_ * g_.H;
-  block_ = nh <= 256 ? 64 : (nh <= 2048 ? 128 : 256);
+  block_ = nh <= 128 ? 64 : (nh <= 384 ? 128 : 256);  // measured on MI355X: 1dx6f (546 pairs) 256 > 128 > 64
   block_ = env_int("RBL_CFR_BLOCK", block_);
+  if (env_int("RBL_CFR_DBG", 0)) {
+    d_dbg_.alloc(L * 16);
+    RBL_HIP_CHECK(hipMemset(d_dbg_.p, 0, L * 16 * sizeof(long long)));
+  }
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -341,6 +345,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.pos = pos;
   a.neg = neg;
   a.strat = strat;
+  a.dbg = d_dbg_.p && env_int("RBL_CFR_DBG", 0) ? d_dbg_.p : nullptr;
   time_begin(0);
   launch_cfr(a, B_, block_, lds_bytes_, stream_);
   time_end(0);
@@ -528,6 +533,12 @@ void Engine::examples(int lane, float* queries, float* values) {  // update_valu
     write_root_query(t, h_bid_[lane], h_player_[lane], b, b + H, queries + (size_t)t * Q);
     for (int h = 0; h < H; ++h) values[t * H + h] = (float)rm[t * H + h];  // double -> float (:224)
   }
+}
+
+void Engine::get_debug(long long* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  if (d_dbg_.p) RBL_HIP_CHECK(hipMemcpy(out, d_dbg_.p, (size_t)B_ * 16 * sizeof(long long), hipMemcpyDeviceToHost));
 }
 
 void Engine::get_queries(float* out) {
@@ -815,6 +826,7 @@ int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values) 
   return guard([&] { e->impl.examples(lane, queries, values); });
 }
 int rbl_solver_get_queries(rbl_engine* e, float* out) { return guard([&] { e->impl.get_queries(out); }); }
+int rbl_solver_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { e->impl.get_debug(out); }); }
 
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
                                   int sample_leaf) {

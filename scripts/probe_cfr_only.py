@@ -1,0 +1,9 @@
+"""Runs only CFR steps (synthetic elementwise net) on 4096 root lanes -- for rocprofv3 PMC runs of cfr_step_kernel."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+from rebel_amd import capi
+B = 4096
+e = capi.Engine(1, 6, capi.make_params(num_iters=1024, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
+e.set_net_synthetic()
+e.reset([-1]*B, [0]*B, np.full((B, 2, e.H), 1.0/e.H))
+e.multistep(int(sys.argv[1]) if len(sys.argv) > 1 else 6); e.sync()
