@@ -48,6 +48,7 @@ struct CfrArgs {
   size_t work_stride;
   int use_lds;
   // ---- uniform step parameters (lanes are in lock-step)
+  int lane0;  // first lane of this launch (half-batches run on separate streams)
   int mode, trav, next_trav, steps_after;
   double alpha;            // root-mean step size (subgame_solving.cc:580-590)
   double pos, neg, strat;  // discounts (:592-617)

@@ -77,7 +77,7 @@ __device__ __forceinline__ void sweep_reach(const LaneView& v, const double* sig
 
 __global__ void cfr_step_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
-  const int lane = blockIdx.x;
+  const int lane = a.lane0 + blockIdx.x;
   const int H = a.H, A = a.A, Q = a.Q;
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
   LaneView v;

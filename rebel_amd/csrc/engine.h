@@ -66,7 +66,7 @@ class Engine {
   void set_net_synthetic();
   void set_net_mlp(const rbl_mlp_weights& w);
   void set_net_callback(rbl_net_fn fn, void* user, bool host_buffers);
-  void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev);  // async on stream()
+  void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st = nullptr);  // async
   void net_forward_host(const float* q, int64_t rows, float* out);
 
   // ---- batched solver
@@ -106,15 +106,20 @@ class Engine {
   void expand_dense(int lane, const std::vector<double>& edge, double* out) const;
   void read_lane(const double* dev_base, int lane, std::vector<double>* out);
   struct Timed;
-  void time_begin(int kind);
-  void time_end(int kind);
+  void time_begin(int kind, hipStream_t st);
+  void time_end(int kind, hipStream_t st);
 
   int device_;
   Rules g_;
   rbl_params p_;
   ShapeTables tabs_;
   int max_lanes_, emax_, nmax_;
-  hipStream_t stream_ = nullptr;
+  hipStream_t stream_ = nullptr, stream2_ = nullptr;
+  hipEvent_t ev_ready_ = nullptr;
+  int n_parts_ = 1, only_part_ = -1, split_min_lanes_ = 1024;
+  int part_lane_[3] = {0, 0, 0};
+  int64_t part_row_[3] = {0, 0, 0};
+  double part_bytes_[2][2] = {{0, 0}, {0, 0}};
 
   DevBuf<ShapeDev> d_shapes_;
   DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_;

@@ -41,6 +41,9 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   if (device < 0 || device >= ndev) throw std::runtime_error("engine: no such HIP device " + std::to_string(device));
   RBL_HIP_CHECK(hipSetDevice(device_));
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+  split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
 
   tabs_ = ShapeTables::build(g_, p_.max_depth);
   nmax_ = tabs_.max_N;
@@ -96,8 +99,11 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
 Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
+  if (stream2_) (void)hipStreamSynchronize(stream2_);
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
+  if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (stream_) (void)hipStreamDestroy(stream_);
+  if (stream2_) (void)hipStreamDestroy(stream2_);
 }
 
 void Engine::check_lane(int lane) const {
@@ -141,8 +147,9 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   const int tile = env_int("RBL_MLP_TILE", 2);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
-  // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches on the engine stream
-  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be
+  // enqueued while we hold net_mutex_, and the ones already enqueued on either stream are drained first
+  sync();
   d_mlp_blob_.upload(pk.blob, stream_);
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   mlp_ = MlpDev{};
@@ -172,31 +179,32 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   values_zeroed_ = false;
 }
 
-void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev) {
+void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st) {
   if (rows <= 0) return;
+  if (!st) st = stream_;
   const int Q = g_.query_size(), H = g_.H;
   switch (net_mode_) {
     case NetMode::kZero:
-      RBL_HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)rows * H * sizeof(float), stream_));
+      RBL_HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)rows * H * sizeof(float), st));
       break;
     case NetMode::kSynthetic:
-      launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, stream_);
+      launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, st);
       break;
     case NetMode::kMlp:
-      launch_mlp_forward(mlp_, q_dev, rows, out_dev, stream_);
+      launch_mlp_forward(mlp_, q_dev, rows, out_dev, st);
       break;
     case NetMode::kCallback:
       if (cb_host_) {
         h_q_.resize((size_t)rows * Q);
         h_v_.assign((size_t)rows * H, 0.f);
-        RBL_HIP_CHECK(hipMemcpyAsync(h_q_.data(), q_dev, h_q_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+        RBL_HIP_CHECK(hipMemcpyAsync(h_q_.data(), q_dev, h_q_.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        RBL_HIP_CHECK(hipStreamSynchronize(st));
         cb_fn_(cb_user_, h_q_.data(), rows, Q, h_v_.data(), H, nullptr);
-        RBL_HIP_CHECK(hipMemcpyAsync(out_dev, h_v_.data(), h_v_.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
-        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+        RBL_HIP_CHECK(hipMemcpyAsync(out_dev, h_v_.data(), h_v_.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        RBL_HIP_CHECK(hipStreamSynchronize(st));
       } else {  // device pointers: the engine stream is drained first; the callee returns with `out` complete
-        RBL_HIP_CHECK(hipStreamSynchronize(stream_));
-        cb_fn_(cb_user_, q_dev, rows, Q, out_dev, H, (void*)stream_);
+        RBL_HIP_CHECK(hipStreamSynchronize(st));
+        cb_fn_(cb_user_, q_dev, rows, Q, out_dev, H, (void*)st);
       }
       break;
   }
@@ -204,6 +212,7 @@ void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev) {
 }
 
 void Engine::net_forward_host(const float* q, int64_t rows, float* out) {
+  sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (rows <= 0) return;
   const size_t nq = (size_t)rows * g_.query_size(), no = (size_t)rows * g_.H;
@@ -221,26 +230,26 @@ void Engine::timing(int stride) {
   timing_ = timing_stride_ > 0;
 }
 
-void Engine::time_begin(int kind) {
+void Engine::time_begin(int kind, hipStream_t st) {
   if (!timed_now()) return;
   while (ev_pool_.size() < ev_used_ + 2) {
     hipEvent_t e;
     RBL_HIP_CHECK(hipEventCreate(&e));
     ev_pool_.push_back(e);
   }
-  RBL_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_], stream_));
+  RBL_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_], st));
   pending_.push_back(Pending{kind, ev_used_, ev_used_ + 1});
   ev_used_ += 2;
 }
 
-void Engine::time_end(int) {
+void Engine::time_end(int, hipStream_t st) {
   if (!timed_now()) return;
-  RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], stream_));
+  RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], st));
 }
 
 void Engine::stats(rbl_kernel_stats* out, bool reset) {
   RBL_HIP_CHECK(hipSetDevice(device_));
-  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  sync();
   for (const auto& p : pending_) {
     float ms = 0;
     RBL_HIP_CHECK(hipEventElapsedTime(&ms, ev_pool_[p.e0], ev_pool_[p.e1]));
@@ -256,6 +265,7 @@ void Engine::stats(rbl_kernel_stats* out, bool reset) {
 void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_player, const double* beliefs,
                    const int32_t* act_iteration) {
   RBL_HIP_CHECK(hipSetDevice(device_));
+  sync();
   if (B < 1 || B > max_lanes_) throw std::runtime_error("reset: B must be in [1, max_lanes]");
   const int H = g_.H, Q = g_.query_size();
   h_shape_.resize(B);
@@ -299,6 +309,30 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_lane_row_.upload(h_row_, stream_);
   d_lane_act_.upload(h_act_, stream_);
   d_beliefs_.upload(h_beliefs_, stream_);
+  // two half-batches on two streams: one half's CFR step overlaps the other half's value-net forward (the two
+  // kernels stress different units); halves are independent lane sets, rows of a half are contiguous
+  n_parts_ = (B >= 2 * split_min_lanes_) ? 2 : 1;
+  part_lane_[0] = 0;
+  part_lane_[1] = n_parts_ == 2 ? B / 2 : B;
+  part_lane_[2] = B;
+  part_row_[0] = 0;
+  part_row_[1] = n_parts_ == 2 ? h_row_[B / 2] : rows;
+  part_row_[2] = rows;
+  for (int t = 0; t < 2; ++t) {
+    part_bytes_[0][t] = part_bytes_[1][t] = 0;
+  }
+  for (int b = 0; b < B; ++b) {
+    const ShapeDev& s = tabs_.shapes[h_shape_[b]];
+    int e_par[2] = {0, 0};
+    for (int n = 1; n < s.N; ++n) ++e_par[tabs_.depth[s.node_off + tabs_.parent[s.node_off + n]] & 1];
+    const int part = (n_parts_ == 2 && b >= B / 2) ? 1 : 0;
+    for (int t = 0; t < 2; ++t) {
+      const int et = e_par[(h_player_[b] == t) ? 0 : 1];
+      part_bytes_[part][t] += 8.0 * H * ((s.N - 1) + 5.0 * et) + 4.0 * s.L * (Q + H);
+    }
+  }
+  RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
+  RBL_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_ready_, 0));
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
 }
@@ -346,16 +380,23 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.neg = neg;
   a.strat = strat;
   a.dbg = d_dbg_.p && env_int("RBL_CFR_DBG", 0) ? d_dbg_.p : nullptr;
-  time_begin(0);
-  launch_cfr(a, B_, block_, lds_bytes_, stream_);
-  time_end(0);
-  RBL_HIP_CHECK(hipGetLastError());
-  if (mode == kModeStep) {
-    if (timed_now()) {
-      ++stats_.cfr_launches;
-      stats_.cfr_bytes += step_bytes_[trav];
+  for (int part = 0; part < n_parts_; ++part) {
+    if (only_part_ >= 0 && part != only_part_) continue;
+    const int l0 = part_lane_[part], cnt = part_lane_[part + 1] - l0;
+    if (cnt <= 0) continue;
+    hipStream_t st = part == 0 ? stream_ : stream2_;
+    a.lane0 = l0;
+    time_begin(0, st);
+    launch_cfr(a, cnt, block_, lds_bytes_, st);
+    time_end(0, st);
+    RBL_HIP_CHECK(hipGetLastError());
+    if (mode == kModeStep) {
+      if (timed_now()) {
+        ++stats_.cfr_launches;
+        stats_.cfr_bytes += part_bytes_[part][trav];
+      }
+      stats_.lane_steps += cnt;
     }
-    stats_.lane_steps += B_;
   }
 }
 
@@ -364,21 +405,30 @@ void Engine::run_net() {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (net_mode_ == NetMode::kZero) {
     if (!values_zeroed_) {
+      sync();
       RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
+      RBL_HIP_CHECK(hipStreamSynchronize(stream_));
       values_zeroed_ = true;
     }
     return;
   }
-  const bool timed = net_mode_ == NetMode::kMlp && timed_now();
-  if (timed) time_begin(1);
-  net_forward_dev(d_queries_.p, rows_, d_values_.p);
-  if (timed) {
-    time_end(1);
-    ++stats_.net_launches;
-    stats_.net_rows += rows_;
-    stats_.net_flops += 2.0 * (double)rows_ *
-                        ((double)mlp_.n_in * mlp_.n_hidden + (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
-                         (double)mlp_.n_hidden * mlp_.n_out);
+  const int Q = g_.query_size(), H = g_.H;
+  for (int part = 0; part < n_parts_; ++part) {
+    if (only_part_ >= 0 && part != only_part_) continue;
+    const int64_t r0 = part_row_[part], nr = part_row_[part + 1] - r0;
+    if (nr <= 0) continue;
+    hipStream_t st = part == 0 ? stream_ : stream2_;
+    const bool timed = net_mode_ == NetMode::kMlp && timed_now();
+    if (timed) time_begin(1, st);
+    net_forward_dev(d_queries_.p + r0 * Q, nr, d_values_.p + r0 * H, st);
+    if (timed) {
+      time_end(1, st);
+      ++stats_.net_launches;
+      stats_.net_rows += nr;
+      stats_.net_flops += 2.0 * (double)nr *
+                          ((double)mlp_.n_in * mlp_.n_hidden + (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
+                           (double)mlp_.n_hidden * mlp_.n_out);
+    }
   }
 }
 
@@ -390,7 +440,6 @@ void Engine::step(int traverser) {
     launch(kModeQueries, 0, traverser, 0, 0, 1, 1, 1);
     pending_trav_ = traverser;
   }
-  run_net();
   const int k = num_steps_[traverser];
   // running mean step (subgame_solving.cc:580-590) and discounts (:592-617); "+1": the uniform strategy counts
   const double alpha = p_.linear_update ? 2. / (k + 2) : 1. / (k + 1);
@@ -405,7 +454,12 @@ void Engine::step(int traverser) {
       strat = std::pow(s / (s + 1), p_.dcfr_gamma);
     }
   }
-  launch(kModeStep, traverser, 1 - traverser, iter_ + 1, alpha, pos, neg, strat);
+  for (int part = 0; part < n_parts_; ++part) {  // per stream: net forward, then the CFR step that consumes it
+    only_part_ = part;
+    run_net();
+    launch(kModeStep, traverser, 1 - traverser, iter_ + 1, alpha, pos, neg, strat);
+  }
+  only_part_ = -1;
   ++num_steps_[traverser];
   ++iter_;
   pending_trav_ = 1 - traverser;
@@ -419,6 +473,7 @@ void Engine::multistep(int n) {
 void Engine::sync() {
   RBL_HIP_CHECK(hipSetDevice(device_));
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream2_));
 }
 
 int Engine::tree_size(int lane) const {
@@ -427,6 +482,7 @@ int Engine::tree_size(int lane) const {
 }
 
 void Engine::read_lane(const double* dev_base, int lane, std::vector<double>* out) {
+  sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   const size_t eh = (size_t)emax_ * g_.H;
   out->resize(eh);
@@ -501,6 +557,7 @@ void Engine::get_snapshot(int lane, double* out) {
 }
 
 void Engine::hand_values(int lane, int player, double* out) {
+  sync();
   check_lane(lane);
   if (player != 0 && player != 1) throw std::runtime_error("hand_values: player must be 0 or 1");
   RBL_HIP_CHECK(hipSetDevice(device_));
@@ -520,7 +577,8 @@ void Engine::write_root_query(int traverser, int last_bid, int player, const dou
   normalize_safe(b1, g_.H, kEps, q + w);
 }
 
-void Engine::examples(int lane, float* queries, float* values) {  // update_value_network, subgame_solving.cc:672-676
+void Engine::examples(int lane, float* queries, float* values) {
+  sync();  // update_value_network, subgame_solving.cc:672-676
   check_lane(lane);
   const int H = g_.H, Q = g_.query_size();
   std::vector<double> rm(2 * H);
@@ -536,12 +594,14 @@ void Engine::examples(int lane, float* queries, float* values) {  // update_valu
 }
 
 void Engine::get_debug(long long* out) {
+  sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   if (d_dbg_.p) RBL_HIP_CHECK(hipMemcpy(out, d_dbg_.p, (size_t)B_ * 16 * sizeof(long long), hipMemcpyDeviceToHost));
 }
 
 void Engine::get_queries(float* out) {
+  sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (rows_ > 0)
     RBL_HIP_CHECK(hipMemcpyAsync(out, d_queries_.p, (size_t)rows_ * g_.query_size() * sizeof(float),
@@ -550,6 +610,7 @@ void Engine::get_queries(float* out) {
 }
 
 void Engine::read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean) {
+  sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   const size_t eh = (size_t)emax_ * g_.H;
   snap->resize((size_t)B_ * eh);
