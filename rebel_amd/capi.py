@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librebel_hip.so")
+LIB_PATH = os.environ.get("REBEL_HIP_LIB") or os.path.join(HERE, "librebel_hip.so")  # override: A/B builds
 
 GET_AVERAGE, GET_LAST, GET_REGRETS, GET_SUM = 0, 1, 2, 3
 

@@ -571,6 +571,9 @@ __device__ __forceinline__ void split_tiles(const f32x4& t0, const f32x4& t1, f1
 // chunk c+1 visible to all waves AND proves that everybody is done with chunk c-1, whose slot is refilled with chunk c+3
 // right away.  Because chunk c+1 is already visible while chunk c is being multiplied, the LDS->register fragment ring
 // (PF k-steps ahead, pinned with sched_barrier) runs straight across chunk boundaries.
+#ifndef RBL_NET_LDS_PAD_F4
+#define RBL_NET_LDS_PAD_F4 0
+#endif
 constexpr int kSlotF4 = 1024;  // f32x4 (16-byte) units per 16 KiB ring slot
 constexpr int kSlots = 4;
 
@@ -578,7 +581,9 @@ template <int OT>
 __global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                    int64_t rows, float* __restrict__ out) {
   constexpr int NT = 16, KS = 8, PF = 3;
-  __shared__ f32x4 ring[kSlots * kSlotF4];
+  __shared__ f32x4 ring[kSlots * kSlotF4 + RBL_NET_LDS_PAD_F4];
+  if (m.stagger == 1) stagger_priority();
+  if (m.stagger >= 2) stagger_sleep(blockIdx.x >= 256 && blockIdx.x < 512, m.stagger);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 15, g = lane >> 4;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + j;
