@@ -105,6 +105,8 @@ int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values);
 int rbl_solver_get_queries(rbl_engine* e, float* out);
 /* developer aid (env RBL_CFR_DBG=1 at engine creation): out[B][16] shader-clock stamps of the last CFR launch's phases */
 int rbl_solver_debug_stamps(rbl_engine* e, long long* out);
+/* developer aid (env RBL_NET_DBG=1): out[1024][16] shader-clock stamps of the last net forward's first 1024 workgroups */
+int rbl_net_debug_stamps(rbl_engine* e, long long* out);
 
 /* ---- self-play lanes: RlRunner (recursive_solving.h:40-86), one per seed (create_cfr_thread, pybind.cc:36-43) ---- */
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_engine_timing", "rbl_engine_stats",
 ]
@@ -102,6 +102,7 @@ def lib():
         "rbl_solver_examples": (C.c_int, [vp, C.c_int, fp, fp]),
         "rbl_solver_get_queries": (C.c_int, [vp, fp]),
         "rbl_solver_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
+        "rbl_net_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_selfplay_create": (vp, [vp, C.c_int, i32p, C.c_double, C.c_int]),
         "rbl_selfplay_destroy": (None, [vp]),
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
@@ -277,6 +278,11 @@ class Engine:
     def debug_stamps(self):
         out = np.zeros((self.B, 16), np.int64)
         _check(self.L.rbl_solver_debug_stamps(self.h, _p(out, C.c_longlong)))
+        return out
+
+    def net_debug_stamps(self):
+        out = np.zeros((1024, 16), np.int64)
+        _check(self.L.rbl_net_debug_stamps(self.h, _p(out, C.c_longlong)))
         return out
 
     # ---- accounting

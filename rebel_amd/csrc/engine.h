@@ -83,7 +83,8 @@ class Engine {
   void hand_values(int lane, int player, double* out);
   void examples(int lane, float* queries, float* values);
   void get_queries(float* out);
-  void get_debug(long long* out);  // RBL_CFR_DBG=1: per-lane phase timestamps of the last CFR launch
+  void get_debug(long long* out);
+  void get_net_debug(long long* out);  // RBL_NET_DBG=1: phase stamps of the last net forward (first 1024 workgroups)  // RBL_CFR_DBG=1: per-lane phase timestamps of the last CFR launch
 
   // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
   void read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean);
@@ -126,7 +127,7 @@ class Engine {
   DevBuf<int8_t> d_matches_;
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
-  DevBuf<long long> d_dbg_;
+  DevBuf<long long> d_dbg_, d_ndbg_;
   DevBuf<float> d_queries_, d_values_, d_mlp_blob_, d_tmp_q_, d_tmp_o_;
 
   std::vector<int> h_shape_, h_player_, h_row_, h_act_, h_bid_;

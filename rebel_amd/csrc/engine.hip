@@ -144,7 +144,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   if (w.n_out != g_.H)
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
-  const int tile = env_int("RBL_MLP_TILE", 2);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
+  const int tile = env_int("RBL_MLP_TILE", 3);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be
@@ -159,6 +159,10 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   mlp_.n_out = w.n_out;
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
   mlp_.tile = pk.tile;
+  if (env_int("RBL_NET_DBG", 0)) {
+    if (!d_ndbg_.p) d_ndbg_.alloc(1024 * 16);
+    mlp_.dbg = d_ndbg_.p;
+  }
   mlp_.stagger = env_int("RBL_MLP_STAGGER", 0);
   for (size_t i = 0; i < pk.inv_scale.size() && i < 8; ++i) mlp_.inv_scale[i] = pk.inv_scale[i];
   mlp_.tape_chunks = pk.tape_chunks;
@@ -593,6 +597,11 @@ void Engine::examples(int lane, float* queries, float* values) {
   }
 }
 
+void Engine::get_net_debug(long long* out) {
+  sync();
+  if (d_ndbg_.p) RBL_HIP_CHECK(hipMemcpy(out, d_ndbg_.p, 1024 * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+}
+
 void Engine::get_debug(long long* out) {
   sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
@@ -888,6 +897,7 @@ int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values) 
 }
 int rbl_solver_get_queries(rbl_engine* e, float* out) { return guard([&] { e->impl.get_queries(out); }); }
 int rbl_solver_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { e->impl.get_debug(out); }); }
+int rbl_net_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { e->impl.get_net_debug(out); }); }
 
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
                                   int sample_leaf) {

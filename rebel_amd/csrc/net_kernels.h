@@ -14,7 +14,8 @@ struct MlpDev {
   const float* tape = nullptr;  // variant 0: the packed weights in consumption order, 32 KiB chunks
   int tape_chunks = 0, l0_chunks = 0;
   float inv_scale[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // variant 2: 1 / (power-of-two weight scale) per layer (last = output)
-  int stagger = 0;    // static wave priority by hardware slot parity (see stagger_priority)
+  int stagger = 0;
+  long long* dbg = nullptr;  // developer aid: [1024][16] phase stamps of the first 1024 workgroups (fsplit kernel)    // static wave priority by hardware slot parity (see stagger_priority)
   int k0_steps = 0;   // layer-0 k-pairs, padded to a multiple of 4
   int out_tiles = 0;  // ceil(n_out / 32)
   float ln_eps = 1e-5f;

@@ -741,6 +741,247 @@ __global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev 
   }
 }
 
+
+// ================================================================================================ feature-split variant
+// The tape kernels above stream the WEIGHTS through LDS and synchronise the workgroup once per 16 KiB chunk (every ~24
+// MFMAs per wave); PMC showed waves parked on those barriers / LDS waits 40 % of the time and every MFMA needing a fresh
+// 1 KiB fragment from LDS.  This variant turns the sharing around:
+//   * a workgroup = 8 waves = 64 batch rows (4 row tiles); wave w owns OUTPUT FEATURES [32w, 32w+32) of every layer.
+//     Its weight fragments are needed by nobody else, so they go L2 -> registers directly (each weight byte is read
+//     once per workgroup, as before) -- no LDS ring, no per-chunk barrier;
+//   * activations are what the waves exchange, through LDS, once per layer: the GEMM writes its [64 x 32] slab of
+//     pre-activations into a row-major f32 image; after a barrier LayerNorm + GELU run row-parallel (8 threads per
+//     row, 32 features each), and the result is written back -- already f16x2-split and already in MFMA B-operand
+//     order -- over the same bytes for the next layer.  3 barriers per layer instead of 16-19;
+//   * each B fragment read from LDS now feeds 6 MFMAs (2 output tiles x 3 split products) and each weight fragment 4
+//     row tiles, so LDS bytes per MFMA drop 4x; accumulators (64 VGPRs) are the only per-wave activation state, which
+//     lets 4 waves share a SIMD (2 workgroups per CU) and hide each other's latencies.
+constexpr int kFsRows = 64;        // rows per workgroup
+constexpr int kFsYStride = 260;    // f32 per row of the pre-activation image (+4: conflict-free 16-byte column writes)
+constexpr int kFsLdsBytes = kFsRows * kFsYStride * 4;  // 66 560 B >= the 64 KiB f16x2 activation image
+
+template <int OT>
+__global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev m, const float* __restrict__ queries,
+                                                                    int64_t rows, float* __restrict__ out) {
+  constexpr int KS = 8, RT = 4;
+  __shared__ __align__(16) unsigned char smem[kFsLdsBytes];
+  float* Y = reinterpret_cast<float*>(smem);        // [64][260] f32
+  f32x4* X = reinterpret_cast<f32x4*>(smem);        // [ks][part h,l][row tile][lane] 16-byte units (8 halves)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * kFsRows;
+  constexpr float kLo = 1.0f / 2048.0f;
+  long long* dbg = m.dbg && blockIdx.x < 1024 ? m.dbg + (size_t)blockIdx.x * 16 : nullptr;
+  int dbg_k = 0;
+#define RBL_NSTAMP()                                              \
+  do {                                                            \
+    if (dbg && tid == 0) dbg[dbg_k] = (long long)clock64();       \
+    ++dbg_k;                                                      \
+  } while (0)
+  RBL_NSTAMP();
+
+  // ---------------------------------------------------------------- stage the query rows as f16x2 B fragments
+  if (tid < 256) {
+    const int rt = tid >> 6;
+    const int64_t row = row0 + rt * 16 + j;
+    const bool valid = row < rows;
+    const float* qrow = queries + (valid ? row : 0) * m.n_in;
+    for (int ks = 0; ks < m.l0_chunks; ++ks) {
+      float q8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * ks + 8 * g + e;
+        q8[e] = (valid && k < m.n_in) ? qrow[k] : 0.f;
+      }
+      f16x2 h[4], l[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split2(q8[2 * e], q8[2 * e + 1], &h[e], &l[e]);
+      Frag16 fh, fl;
+      fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+      fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+      X[((ks * 2 + 0) * RT + rt) * 64 + lane] = fh.v;
+      X[((ks * 2 + 1) * RT + rt) * 64 + lane] = fl.v;
+    }
+  }
+  __syncthreads();
+
+  // one dense layer for this wave's 2 output tiles x 4 row tiles; wg = the wave's fragments [ks][ot][part][lane]
+  f32x4 acc1[2][RT], acc2[2][RT];
+  auto gemm = [&](const f32x4* __restrict__ wg, int nks) {
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc1[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc2[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    Frag16 wh[2], wl[2], nh[2], nl[2];
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      wh[ot].v = wg[(ot * 2 + 0) * 64 + lane];
+      wl[ot].v = wg[(ot * 2 + 1) * 64 + lane];
+    }
+    for (int ks = 0; ks < nks; ++ks) {
+      if (ks + 1 < nks) {  // next k-step's weights are in flight while this one is multiplied
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          nh[ot].v = wg[(((ks + 1) * 2 + ot) * 2 + 0) * 64 + lane];
+          nl[ot].v = wg[(((ks + 1) * 2 + ot) * 2 + 1) * 64 + lane];
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        Frag16 xh, xl;
+        xh.v = X[((ks * 2 + 0) * RT + rt) * 64 + lane];
+        xl.v = X[((ks * 2 + 1) * RT + rt) * 64 + lane];
+        acc2[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0].h, xh.h, acc2[0][rt], 0, 0, 0);
+        acc2[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1].h, xh.h, acc2[1][rt], 0, 0, 0);
+        acc1[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0].h, xh.h, acc1[0][rt], 0, 0, 0);
+        acc1[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1].h, xh.h, acc1[1][rt], 0, 0, 0);
+        acc2[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0].h, xl.h, acc2[0][rt], 0, 0, 0);
+        acc2[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1].h, xl.h, acc2[1][rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        wh[ot] = nh[ot];
+        wl[ot] = nl[ot];
+      }
+    }
+  };
+
+  // pre-activations (+ bias) of this wave's 32 features -> row-major image; everybody must be done READING X first
+  auto write_y = [&](float inv_s, const float* __restrict__ bias) {
+    __syncthreads();
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      const int f0 = 32 * wave + 16 * ot + 4 * g;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 v = (acc1[ot][rt] + acc2[ot][rt] * kLo) * inv_s + b4;
+        *reinterpret_cast<f32x4*>(&Y[(rt * 16 + j) * kFsYStride + f0]) = v;
+      }
+    }
+    __syncthreads();
+  };
+
+  // LayerNorm + GELU, row-parallel: thread (row = tid>>3, fg = tid&7) owns features {32 i + 4 fg + r}; the result is
+  // written back over the same bytes as f16x2 B fragments in natural k order (k-step i, lane group fg>>1, half fg&1)
+  auto epilogue_rows = [&](const float* __restrict__ ln_w, const float* __restrict__ ln_b) {
+    const int row = tid >> 3, fg = tid & 7;
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(&Y[row * kFsYStride + 32 * i + 4 * fg]);
+    __syncthreads();  // the image is about to be overwritten by the next layer's operands
+    if (m.use_ln == 2) {
+    } else if (m.use_ln) {
+      f32x2 s2 = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += f32x2{v[i][0], v[i][1]} + f32x2{v[i][2], v[i][3]};
+      float s = s2[0] + s2[1];
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      const float mean = s * (1.0f / 256.0f);
+      f32x2 q2 = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 d0 = f32x2{v[i][0], v[i][1]} - splat2(mean), d1 = f32x2{v[i][2], v[i][3]} - splat2(mean);
+        q2 = fma2(d0, d0, q2);
+        q2 = fma2(d1, d1, q2);
+      }
+      float vs = q2[0] + q2[1];
+      vs += __shfl_xor(vs, 1);
+      vs += __shfl_xor(vs, 2);
+      vs += __shfl_xor(vs, 4);
+      const float rstd = 1.0f / sqrtf(vs * (1.0f / 256.0f) + m.ln_eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(ln_w + 32 * i + 4 * fg);
+        const f32x4 o4 = *reinterpret_cast<const f32x4*>(ln_b + 32 * i + 4 * fg);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 a = f32x2{g4[2 * h2], g4[2 * h2 + 1]} * splat2(rstd);
+          const f32x2 b = fma2(splat2(-mean), a, f32x2{o4[2 * h2], o4[2 * h2 + 1]});
+          const f32x2 y = gelu2(fma2(f32x2{v[i][2 * h2], v[i][2 * h2 + 1]}, a, b));
+          v[i][2 * h2] = y[0];
+          v[i][2 * h2 + 1] = y[1];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 y = gelu2(f32x2{v[i][2 * h2], v[i][2 * h2 + 1]});
+          v[i][2 * h2] = y[0];
+          v[i][2 * h2 + 1] = y[1];
+        }
+    }
+    const int rt = row >> 4, lane2 = (fg >> 1) * 16 + (row & 15);
+    unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      f16x2 h0, l0, h1, l1;
+      split2(v[i][0], v[i][1], &h0, &l0);
+      split2(v[i][2], v[i][3], &h1, &l1);
+      typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+      const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      X8[(((i * 2 + 0) * RT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, hh);
+      X8[(((i * 2 + 1) * RT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, ll);
+    }
+    __syncthreads();
+  };
+
+  const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
+  RBL_NSTAMP();  // 1: queries staged
+  // ---------------------------------------------------------------- layer 0
+  gemm(blob + (size_t)wave * m.l0_chunks * 4 * 64, m.l0_chunks);
+  RBL_NSTAMP();  // 2: L0 gemm
+  write_y(m.inv_scale[0], m.bias);
+  RBL_NSTAMP();  // 3: L0 y written
+  epilogue_rows(m.ln_w, m.ln_b);
+  RBL_NSTAMP();  // 4: L0 epilogue
+  // ---------------------------------------------------------------- hidden layers
+  for (int l = 1; l < m.n_layers; ++l) {
+    const f32x4* wl = reinterpret_cast<const f32x4*>(m.wh) + ((size_t)(l - 1) * 8 + wave) * KS * 4 * 64;
+    gemm(wl, KS);
+    RBL_NSTAMP();  // 5: hidden gemm
+    write_y(m.inv_scale[l], m.bias + l * 256);
+    RBL_NSTAMP();  // 6: hidden y written
+    epilogue_rows(m.ln_w + l * 256, m.ln_b + l * 256);
+    RBL_NSTAMP();  // 7: hidden epilogue
+  }
+  // ---------------------------------------------------------------- output layer: (tile, row tile) pairs over the waves
+  for (int p = wave; p < OT * RT; p += 8) {
+    const int ot = p / RT, rt = p % RT;
+    const f32x4* wo = reinterpret_cast<const f32x4*>(m.wo) + (size_t)ot * KS * 2 * 64;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Frag16 wh, wl, xh, xl;
+      wh.v = wo[(ks * 2 + 0) * 64 + lane];
+      wl.v = wo[(ks * 2 + 1) * 64 + lane];
+      xh.v = X[((ks * 2 + 0) * RT + rt) * 64 + lane];
+      xl.v = X[((ks * 2 + 1) * RT + rt) * 64 + lane];
+      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl.h, xh.h, a2, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, xh.h, a1, 0, 0, 0);
+      a3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh.h, xl.h, a3, 0, 0, 0);
+    }
+    const f32x4 o = (a1 + (a2 + a3) * kLo) * m.inv_scale[m.n_layers];
+    const int64_t row = row0 + rt * 16 + j;
+    if (row < rows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ot * 16 + 4 * g + r;
+        if (i < m.n_out) out[row * m.n_out + i] = o[r] + m.b_out[i];
+      }
+    }
+  }
+  RBL_NSTAMP();  // 8: output layer
+#undef RBL_NSTAMP
+}
+
 }  // namespace
 
 bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out) {
@@ -938,14 +1179,99 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
   return p;
 }
 
+// feature-split layout (tile = 3): fragments of 64 lanes x 8 halves, natural k order k = 32 ks + 8 g + e.
+//   layer 0 : [wave 8][k-step][tile-in-wave 2][part h,l]     (output features 32 w + 16 ot + (lane & 15))
+//   hidden  : [layer][wave 8][k-step 8][tile-in-wave 2][part]
+//   output  : [tile][k-step 8][part]
+static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
+                                 const float* const* b, const float* const* ln_w, const float* const* ln_b,
+                                 const float* w_out, const float* b_out) {
+  MlpPacked p;
+  p.tile = 3;
+  const int KS = 8;
+  const int ks0 = (n_in + 31) / 32;
+  p.k0_steps = ks0;
+  p.l0_chunks = ks0;
+  p.out_tiles = (n_out + 15) / 16;
+  const size_t frag_f = 64 * 4;  // floats per fragment (64 lanes x 16 B)
+  const size_t n_w0 = (size_t)8 * ks0 * 4 * frag_f;
+  const size_t n_wh = (size_t)(n_layers - 1) * 8 * KS * 4 * frag_f;
+  const size_t n_wo = (size_t)p.out_tiles * KS * 2 * frag_f;
+  p.off_w0 = 0;
+  p.off_wh = n_w0;
+  p.off_wo = p.off_wh + n_wh;
+  p.off_bias = p.off_wo + n_wo;
+  p.off_lnw = p.off_bias + (size_t)n_layers * n_hidden;
+  p.off_lnb = p.off_lnw + (size_t)n_layers * n_hidden;
+  p.off_bout = p.off_lnb + (size_t)n_layers * n_hidden;
+  p.blob.assign(p.off_bout + (size_t)p.out_tiles * 16, 0.f);
+  p.tape_chunks = 0;
+  _Float16* tape = reinterpret_cast<_Float16*>(p.blob.data());
+  auto scale_of = [](const float* W, size_t n) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(W[i]));
+    if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
+    return std::ldexp(1.0f, (int)std::floor(std::log2(8192.0f / mx)));
+  };
+  auto put = [&](size_t frag, const float* W, int ld, int n_rows, int n_cols, int i0, int ks, float S, int part) {
+    for (int lane = 0; lane < 64; ++lane)
+      for (int e = 0; e < 8; ++e) {
+        const int i = i0 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+        const float v = (i < n_rows && k < n_cols) ? W[(size_t)i * ld + k] * S : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        tape[(frag * 64 + lane) * 8 + e] = part == 0 ? hi : lo;
+      }
+  };
+  p.inv_scale.assign(n_layers + 1, 1.f);
+  {
+    const float S = scale_of(w[0], (size_t)n_hidden * n_in);
+    p.inv_scale[0] = 1.0f / S;
+    for (int wv = 0; wv < 8; ++wv)
+      for (int ks = 0; ks < ks0; ++ks)
+        for (int ot = 0; ot < 2; ++ot)
+          for (int part = 0; part < 2; ++part)
+            put(((size_t)(wv * ks0 + ks) * 2 + ot) * 2 + part, w[0], n_in, n_hidden, n_in, 32 * wv + 16 * ot, ks, S, part);
+  }
+  const size_t frag_wh = p.off_wh / frag_f, frag_wo = p.off_wo / frag_f;
+  for (int l = 1; l < n_layers; ++l) {
+    const float S = scale_of(w[l], (size_t)n_hidden * n_hidden);
+    p.inv_scale[l] = 1.0f / S;
+    for (int wv = 0; wv < 8; ++wv)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int ot = 0; ot < 2; ++ot)
+          for (int part = 0; part < 2; ++part)
+            put(frag_wh + ((((size_t)(l - 1) * 8 + wv) * KS + ks) * 2 + ot) * 2 + part, w[l], n_hidden, n_hidden,
+                n_hidden, 32 * wv + 16 * ot, ks, S, part);
+  }
+  {
+    const float S = scale_of(w_out, (size_t)n_out * n_hidden);
+    p.inv_scale[n_layers] = 1.0f / S;
+    for (int ot = 0; ot < p.out_tiles; ++ot)
+      for (int ks = 0; ks < KS; ++ks)
+        for (int part = 0; part < 2; ++part)
+          put(frag_wo + ((size_t)ot * KS + ks) * 2 + part, w_out, n_hidden, n_out, n_hidden, 16 * ot, ks, S, part);
+  }
+  for (int l = 0; l < n_layers; ++l)
+    for (int i = 0; i < n_hidden; ++i) {
+      p.blob[p.off_bias + (size_t)l * n_hidden + i] = b[l][i];
+      p.blob[p.off_lnw + (size_t)l * n_hidden + i] = use_ln ? ln_w[l][i] : 1.f;
+      p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? ln_b[l][i] : 0.f;
+    }
+  for (int i = 0; i < n_out; ++i) p.blob[p.off_bout + i] = b_out[i];
+  return p;
+}
+
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error("value net shape not supported by the MFMA forward (n_hidden in {64,128,256}, n_out <= 64)");
-  if (tile == 2 && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
+  if (tile == 3 && n_hidden == 256 && n_out <= 64 && n_layers <= 7 && n_in <= 128)
+    return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
+  if ((tile == 2 || tile == 3) && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
     return pack_mlp_f16x2(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
-  if ((tile == 0 || tile == 2) && n_hidden == 256 && n_out <= 64)
+  if ((tile == 0 || tile == 2 || tile == 3) && n_hidden == 256 && n_out <= 64)
     return pack_mlp_tape(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   if (tile != 32) return pack_mlp16(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   MlpPacked p;
@@ -1025,6 +1351,17 @@ static void launch_mlp16(const MlpDev& m, const float* queries, int64_t rows, fl
 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
   if (rows <= 0) return;
+  if (m.tile == 3) {
+    const dim3 grid((unsigned)((rows + 63) / 64)), block(512);
+    switch (m.out_tiles) {
+      case 1: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<1>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 2: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<2>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 3: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<3>, grid, block, 0, stream, m, queries, rows, out); break;
+      case 4: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<4>, grid, block, 0, stream, m, queries, rows, out); break;
+      default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+    }
+    return;
+  }
   if (m.tile == 2) {
     const dim3 grid((unsigned)((rows + 63) / 64)), block(256);
     switch (m.out_tiles) {
