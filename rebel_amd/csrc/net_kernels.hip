@@ -756,14 +756,18 @@ __global__ void __launch_bounds__(256, 2) mlp_f16x2_forward_kernel(const MlpDev 
 //   * each B fragment read from LDS now feeds 6 MFMAs (2 output tiles x 3 split products) and each weight fragment 4
 //     row tiles, so LDS bytes per MFMA drop 4x; accumulators (64 VGPRs) are the only per-wave activation state, which
 //     lets 4 waves share a SIMD (2 workgroups per CU) and hide each other's latencies.
-constexpr int kFsRows = 64;        // rows per workgroup
 constexpr int kFsYStride = 260;    // f32 per row of the pre-activation image (+4: conflict-free 16-byte column writes)
-constexpr int kFsLdsBytes = kFsRows * kFsYStride * 4;  // 66 560 B >= the 64 KiB f16x2 activation image
 
-template <int OT>
-__global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev m, const float* __restrict__ queries,
-                                                                    int64_t rows, float* __restrict__ out) {
-  constexpr int KS = 8, RT = 4;
+// WAVES = 8: 64 rows per workgroup, 32 features per wave, 2 workgroups per CU (66.5 KB LDS each)
+// WAVES = 4: 32 rows per workgroup, 64 features per wave, 4 workgroups per CU (33 KB LDS each): more independent
+//            workgroups to overlap one's LayerNorm/GELU phase with another's MFMA phase, 2x the L2 weight traffic
+template <int OT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const MlpDev m,
+                                                                          const float* __restrict__ queries,
+                                                                          int64_t rows, float* __restrict__ out) {
+  constexpr int KS = 8, RT = WAVES / 2, OTW = 16 / WAVES;  // row tiles per workgroup, output tiles per wave
+  constexpr int kFsRows = RT * 16;
+  constexpr int kFsLdsBytes = kFsRows * kFsYStride * 4;  // >= the f16x2 activation image (rows x 256 x 4 B)
   __shared__ __align__(16) unsigned char smem[kFsLdsBytes];
   float* Y = reinterpret_cast<float*>(smem);        // [64][260] f32
   f32x4* X = reinterpret_cast<f32x4*>(smem);        // [ks][part h,l][row tile][lane] 16-byte units (8 halves)
@@ -781,7 +785,7 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
   RBL_NSTAMP();
 
   // ---------------------------------------------------------------- stage the query rows as f16x2 B fragments
-  if (tid < 256) {
+  if (tid < RT * 64) {
     const int rt = tid >> 6;
     const int64_t row = row0 + rt * 16 + j;
     const bool valid = row < rows;
@@ -806,27 +810,38 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
   __syncthreads();
 
   // one dense layer for this wave's 2 output tiles x 4 row tiles; wg = the wave's fragments [ks][ot][part][lane]
-  f32x4 acc1[2][RT], acc2[2][RT];
+  f32x4 acc1[OTW][RT], acc2[OTW][RT];
   auto gemm = [&](const f32x4* __restrict__ wg, int nks) {
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
+    for (int ot = 0; ot < OTW; ++ot)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         acc1[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc2[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    Frag16 wh[2], wl[2], nh[2], nl[2];
+    constexpr bool kRing = OTW <= 2;  // 2 tiles/wave: double-buffer the k-step's weights; 4 tiles: registers are spent
+    Frag16 wh[OTW], wl[OTW], nh[kRing ? OTW : 1], nl[kRing ? OTW : 1];
+    if (kRing) {
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-      wh[ot].v = wg[(ot * 2 + 0) * 64 + lane];
-      wl[ot].v = wg[(ot * 2 + 1) * 64 + lane];
+      for (int ot = 0; ot < OTW; ++ot) {
+        wh[ot].v = wg[(ot * 2 + 0) * 64 + lane];
+        wl[ot].v = wg[(ot * 2 + 1) * 64 + lane];
+      }
     }
     for (int ks = 0; ks < nks; ++ks) {
-      if (ks + 1 < nks) {  // next k-step's weights are in flight while this one is multiplied
+      if (kRing) {
+        if (ks + 1 < nks) {  // next k-step's weights are in flight while this one is multiplied
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-          nh[ot].v = wg[(((ks + 1) * 2 + ot) * 2 + 0) * 64 + lane];
-          nl[ot].v = wg[(((ks + 1) * 2 + ot) * 2 + 1) * 64 + lane];
+          for (int ot = 0; ot < OTW; ++ot) {
+            nh[kRing ? ot : 0].v = wg[(((ks + 1) * OTW + ot) * 2 + 0) * 64 + lane];
+            nl[kRing ? ot : 0].v = wg[(((ks + 1) * OTW + ot) * 2 + 1) * 64 + lane];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+          wh[ot].v = wg[((ks * OTW + ot) * 2 + 0) * 64 + lane];
+          wl[ot].v = wg[((ks * OTW + ot) * 2 + 1) * 64 + lane];
         }
       }
 #pragma unroll
@@ -834,17 +849,22 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
         Frag16 xh, xl;
         xh.v = X[((ks * 2 + 0) * RT + rt) * 64 + lane];
         xl.v = X[((ks * 2 + 1) * RT + rt) * 64 + lane];
-        acc2[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[0].h, xh.h, acc2[0][rt], 0, 0, 0);
-        acc2[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[1].h, xh.h, acc2[1][rt], 0, 0, 0);
-        acc1[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0].h, xh.h, acc1[0][rt], 0, 0, 0);
-        acc1[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1].h, xh.h, acc1[1][rt], 0, 0, 0);
-        acc2[0][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[0].h, xl.h, acc2[0][rt], 0, 0, 0);
-        acc2[1][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[1].h, xl.h, acc2[1][rt], 0, 0, 0);
-      }
 #pragma unroll
-      for (int ot = 0; ot < 2; ++ot) {
-        wh[ot] = nh[ot];
-        wl[ot] = nl[ot];
+        for (int ot = 0; ot < OTW; ++ot)
+          acc2[ot][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ot].h, xh.h, acc2[ot][rt], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+          acc1[ot][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ot].h, xh.h, acc1[ot][rt], 0, 0, 0);
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot)
+          acc2[ot][rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ot].h, xl.h, acc2[ot][rt], 0, 0, 0);
+      }
+      if (kRing) {
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+          wh[ot] = nh[kRing ? ot : 0];
+          wl[ot] = nl[kRing ? ot : 0];
+        }
       }
     }
   };
@@ -853,8 +873,8 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
   auto write_y = [&](float inv_s, const float* __restrict__ bias) {
     __syncthreads();
 #pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-      const int f0 = 32 * wave + 16 * ot + 4 * g;
+    for (int ot = 0; ot < OTW; ++ot) {
+      const int f0 = 16 * OTW * wave + 16 * ot + 4 * g;
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -936,7 +956,7 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
   const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
   RBL_NSTAMP();  // 1: queries staged
   // ---------------------------------------------------------------- layer 0
-  gemm(blob + (size_t)wave * m.l0_chunks * 4 * 64, m.l0_chunks);
+  gemm(blob + (size_t)wave * m.l0_chunks * OTW * 2 * 64, m.l0_chunks);
   RBL_NSTAMP();  // 2: L0 gemm
   write_y(m.inv_scale[0], m.bias);
   RBL_NSTAMP();  // 3: L0 y written
@@ -944,7 +964,7 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
   RBL_NSTAMP();  // 4: L0 epilogue
   // ---------------------------------------------------------------- hidden layers
   for (int l = 1; l < m.n_layers; ++l) {
-    const f32x4* wl = reinterpret_cast<const f32x4*>(m.wh) + ((size_t)(l - 1) * 8 + wave) * KS * 4 * 64;
+    const f32x4* wl = reinterpret_cast<const f32x4*>(m.wh) + ((size_t)(l - 1) * WAVES + wave) * KS * OTW * 2 * 64;
     gemm(wl, KS);
     RBL_NSTAMP();  // 5: hidden gemm
     write_y(m.inv_scale[l], m.bias + l * 256);
@@ -953,7 +973,7 @@ __global__ void __launch_bounds__(512, 4) mlp_fsplit_forward_kernel(const MlpDev
     RBL_NSTAMP();  // 7: hidden epilogue
   }
   // ---------------------------------------------------------------- output layer: (tile, row tile) pairs over the waves
-  for (int p = wave; p < OT * RT; p += 8) {
+  for (int p = wave; p < OT * RT; p += WAVES) {
     const int ot = p / RT, rt = p % RT;
     const f32x4* wo = reinterpret_cast<const f32x4*>(m.wo) + (size_t)ot * KS * 2 * 64;
     f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
@@ -1185,17 +1205,18 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
 //   output  : [tile][k-step 8][part]
 static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                                  const float* const* b, const float* const* ln_w, const float* const* ln_b,
-                                 const float* w_out, const float* b_out) {
+                                 const float* w_out, const float* b_out, int waves) {
   MlpPacked p;
-  p.tile = 3;
+  p.tile = waves == 4 ? 4 : 3;
+  const int NW = waves == 4 ? 4 : 8, OTW = 16 / NW;
   const int KS = 8;
   const int ks0 = (n_in + 31) / 32;
   p.k0_steps = ks0;
   p.l0_chunks = ks0;
   p.out_tiles = (n_out + 15) / 16;
   const size_t frag_f = 64 * 4;  // floats per fragment (64 lanes x 16 B)
-  const size_t n_w0 = (size_t)8 * ks0 * 4 * frag_f;
-  const size_t n_wh = (size_t)(n_layers - 1) * 8 * KS * 4 * frag_f;
+  const size_t n_w0 = (size_t)NW * ks0 * OTW * 2 * frag_f;
+  const size_t n_wh = (size_t)(n_layers - 1) * NW * KS * OTW * 2 * frag_f;
   const size_t n_wo = (size_t)p.out_tiles * KS * 2 * frag_f;
   p.off_w0 = 0;
   p.off_wh = n_w0;
@@ -1227,22 +1248,23 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
   {
     const float S = scale_of(w[0], (size_t)n_hidden * n_in);
     p.inv_scale[0] = 1.0f / S;
-    for (int wv = 0; wv < 8; ++wv)
+    for (int wv = 0; wv < NW; ++wv)
       for (int ks = 0; ks < ks0; ++ks)
-        for (int ot = 0; ot < 2; ++ot)
+        for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
-            put(((size_t)(wv * ks0 + ks) * 2 + ot) * 2 + part, w[0], n_in, n_hidden, n_in, 32 * wv + 16 * ot, ks, S, part);
+            put(((size_t)(wv * ks0 + ks) * OTW + ot) * 2 + part, w[0], n_in, n_hidden, n_in, 16 * (OTW * wv + ot), ks, S,
+                part);
   }
   const size_t frag_wh = p.off_wh / frag_f, frag_wo = p.off_wo / frag_f;
   for (int l = 1; l < n_layers; ++l) {
     const float S = scale_of(w[l], (size_t)n_hidden * n_hidden);
     p.inv_scale[l] = 1.0f / S;
-    for (int wv = 0; wv < 8; ++wv)
+    for (int wv = 0; wv < NW; ++wv)
       for (int ks = 0; ks < KS; ++ks)
-        for (int ot = 0; ot < 2; ++ot)
+        for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
-            put(frag_wh + ((((size_t)(l - 1) * 8 + wv) * KS + ks) * 2 + ot) * 2 + part, w[l], n_hidden, n_hidden,
-                n_hidden, 32 * wv + 16 * ot, ks, S, part);
+            put(frag_wh + ((((size_t)(l - 1) * NW + wv) * KS + ks) * OTW + ot) * 2 + part, w[l], n_hidden, n_hidden,
+                n_hidden, 16 * (OTW * wv + ot), ks, S, part);
   }
   {
     const float S = scale_of(w_out, (size_t)n_out * n_hidden);
@@ -1267,11 +1289,11 @@ MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, 
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error("value net shape not supported by the MFMA forward (n_hidden in {64,128,256}, n_out <= 64)");
-  if (tile == 3 && n_hidden == 256 && n_out <= 64 && n_layers <= 7 && n_in <= 128)
-    return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
-  if ((tile == 2 || tile == 3) && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
+  if ((tile == 3 || tile == 4) && n_hidden == 256 && n_out <= 64 && n_layers <= 7 && n_in <= 128)
+    return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, tile == 4 ? 4 : 8);
+  if ((tile == 2 || tile == 3 || tile == 4) && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
     return pack_mlp_f16x2(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
-  if ((tile == 0 || tile == 2 || tile == 3) && n_hidden == 256 && n_out <= 64)
+  if ((tile == 0 || tile == 2 || tile == 3 || tile == 4) && n_hidden == 256 && n_out <= 64)
     return pack_mlp_tape(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   if (tile != 32) return pack_mlp16(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
   MlpPacked p;
@@ -1351,15 +1373,28 @@ static void launch_mlp16(const MlpDev& m, const float* queries, int64_t rows, fl
 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
   if (rows <= 0) return;
-  if (m.tile == 3) {
-    const dim3 grid((unsigned)((rows + 63) / 64)), block(512);
-    switch (m.out_tiles) {
-      case 1: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<1>, grid, block, 0, stream, m, queries, rows, out); break;
-      case 2: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<2>, grid, block, 0, stream, m, queries, rows, out); break;
-      case 3: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<3>, grid, block, 0, stream, m, queries, rows, out); break;
-      case 4: hipLaunchKernelGGL(mlp_fsplit_forward_kernel<4>, grid, block, 0, stream, m, queries, rows, out); break;
-      default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+  if (m.tile == 3 || m.tile == 4) {
+#define RBL_FS(OT_, W_) \
+  hipLaunchKernelGGL((mlp_fsplit_forward_kernel<OT_, W_>), dim3((unsigned)((rows + W_ * 8 - 1) / (W_ * 8))), dim3(W_ * 64), \
+                     0, stream, m, queries, rows, out)
+    if (m.tile == 3) {
+      switch (m.out_tiles) {
+        case 1: RBL_FS(1, 8); break;
+        case 2: RBL_FS(2, 8); break;
+        case 3: RBL_FS(3, 8); break;
+        case 4: RBL_FS(4, 8); break;
+        default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+      }
+    } else {
+      switch (m.out_tiles) {
+        case 1: RBL_FS(1, 4); break;
+        case 2: RBL_FS(2, 4); break;
+        case 3: RBL_FS(3, 4); break;
+        case 4: RBL_FS(4, 4); break;
+        default: throw std::runtime_error("launch_mlp_forward: unsupported n_out");
+      }
     }
+#undef RBL_FS
     return;
   }
   if (m.tile == 2) {
