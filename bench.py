@@ -13,7 +13,9 @@ independent lane sets (seeds rank*lanes+i), no data-path collective: "scaling": 
 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
-                measured live with HIP events on the engine stream (every 8th iteration of the timed region)
+                measured live with HIP events on the engine streams (every 8th iteration of the timed region; the
+                two half-batches run on two streams, so a launch covers half the lanes and overlaps the other half's
+                CFR kernel)
   roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration
   cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so, cpu_gen_threads = host cores) timed for a fixed
                 window on this box's host cores -- a reported baseline, not a target.
@@ -152,7 +154,7 @@ def main():
             # achieved = ALGORITHMIC flops 2*rows*(Q*256 + 256*256 + 256*H) per launch / mean launch time; the kernel issues
             # 3 f16 MFMA products per multiply (+ tile padding), so the matrix pipe does ~3.2x this; what bounds the
             # kernel is its f32 VALU epilogue (LayerNorm + erf-GELU on 512 activations per row), see DESIGN.md
-            "roofline": {"kernel": "mlp_f16x2_forward_kernel<1>", "bound": "mfma", "achieved": net_tf,
+            "roofline": {"kernel": "mlp_fsplit_forward_kernel<1,8> (f16x2-split MFMA)", "bound": "mfma", "achieved": net_tf,
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
                          "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),

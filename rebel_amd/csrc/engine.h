@@ -117,10 +117,12 @@ class Engine {
   int max_lanes_, emax_, nmax_;
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_ready_ = nullptr;
-  int n_parts_ = 1, only_part_ = -1, split_min_lanes_ = 1024;
-  int part_lane_[3] = {0, 0, 0};
-  int64_t part_row_[3] = {0, 0, 0};
-  double part_bytes_[2][2] = {{0, 0}, {0, 0}};
+  hipStream_t stream_x_[2] = {nullptr, nullptr};
+  int n_parts_ = 1, max_parts_ = 2, only_part_ = -1, split_min_lanes_ = 1024;
+  int part_lane_[5] = {0, 0, 0, 0, 0};
+  int64_t part_row_[5] = {0, 0, 0, 0, 0};
+  double part_bytes_[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  hipStream_t part_stream(int part) const { return part == 0 ? stream_ : part == 1 ? stream2_ : stream_x_[part - 2]; }
 
   DevBuf<ShapeDev> d_shapes_;
   DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_;

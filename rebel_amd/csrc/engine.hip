@@ -42,6 +42,8 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   RBL_HIP_CHECK(hipSetDevice(device_));
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_x_[i], hipStreamNonBlocking));
+  max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", 2)));
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
 
@@ -100,6 +102,11 @@ Engine::~Engine() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream2_) (void)hipStreamSynchronize(stream2_);
+  for (int i = 0; i < 2; ++i)
+    if (stream_x_[i]) {
+      (void)hipStreamSynchronize(stream_x_[i]);
+      (void)hipStreamDestroy(stream_x_[i]);
+    }
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (stream_) (void)hipStreamDestroy(stream_);
@@ -315,28 +322,26 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_beliefs_.upload(h_beliefs_, stream_);
   // two half-batches on two streams: one half's CFR step overlaps the other half's value-net forward (the two
   // kernels stress different units); halves are independent lane sets, rows of a half are contiguous
-  n_parts_ = (B >= 2 * split_min_lanes_) ? 2 : 1;
-  part_lane_[0] = 0;
-  part_lane_[1] = n_parts_ == 2 ? B / 2 : B;
-  part_lane_[2] = B;
-  part_row_[0] = 0;
-  part_row_[1] = n_parts_ == 2 ? h_row_[B / 2] : rows;
-  part_row_[2] = rows;
-  for (int t = 0; t < 2; ++t) {
-    part_bytes_[0][t] = part_bytes_[1][t] = 0;
+  n_parts_ = 1;
+  while (n_parts_ < max_parts_ && B >= (n_parts_ + 1) * split_min_lanes_) ++n_parts_;
+  for (int pt = 0; pt <= n_parts_; ++pt) {
+    part_lane_[pt] = (int)((int64_t)B * pt / n_parts_);
+    part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
   }
+  for (int pt = 0; pt < 4; ++pt) part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
   for (int b = 0; b < B; ++b) {
     const ShapeDev& s = tabs_.shapes[h_shape_[b]];
     int e_par[2] = {0, 0};
     for (int n = 1; n < s.N; ++n) ++e_par[tabs_.depth[s.node_off + tabs_.parent[s.node_off + n]] & 1];
-    const int part = (n_parts_ == 2 && b >= B / 2) ? 1 : 0;
+    int part = 0;
+    while (part + 1 < n_parts_ && b >= part_lane_[part + 1]) ++part;
     for (int t = 0; t < 2; ++t) {
       const int et = e_par[(h_player_[b] == t) ? 0 : 1];
       part_bytes_[part][t] += 8.0 * H * ((s.N - 1) + 5.0 * et) + 4.0 * s.L * (Q + H);
     }
   }
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
-  RBL_HIP_CHECK(hipStreamWaitEvent(stream2_, ev_ready_, 0));
+  for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
 }
@@ -388,7 +393,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     if (only_part_ >= 0 && part != only_part_) continue;
     const int l0 = part_lane_[part], cnt = part_lane_[part + 1] - l0;
     if (cnt <= 0) continue;
-    hipStream_t st = part == 0 ? stream_ : stream2_;
+    hipStream_t st = part_stream(part);
     a.lane0 = l0;
     time_begin(0, st);
     launch_cfr(a, cnt, block_, lds_bytes_, st);
@@ -421,7 +426,7 @@ void Engine::run_net() {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int64_t r0 = part_row_[part], nr = part_row_[part + 1] - r0;
     if (nr <= 0) continue;
-    hipStream_t st = part == 0 ? stream_ : stream2_;
+    hipStream_t st = part_stream(part);
     const bool timed = net_mode_ == NetMode::kMlp && timed_now();
     if (timed) time_begin(1, st);
     net_forward_dev(d_queries_.p + r0 * Q, nr, d_values_.p + r0 * H, st);
@@ -478,6 +483,7 @@ void Engine::sync() {
   RBL_HIP_CHECK(hipSetDevice(device_));
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   RBL_HIP_CHECK(hipStreamSynchronize(stream2_));
+  for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamSynchronize(stream_x_[i]));
 }
 
 int Engine::tree_size(int lane) const {
