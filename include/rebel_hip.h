@@ -98,6 +98,18 @@ int64_t rbl_solver_total_rows(rbl_engine* e);       /* sum over lanes of pseudo-
 /* dense double[N][H][A]; which = RBL_GET_* (get_strategy / get_sampling_strategy :678-688; regrets, sum_strategies) */
 int rbl_solver_get(rbl_engine* e, int lane, int which, double* out);
 int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out); /* sigma_last at the lane's act_iteration */
+/* ---- evaluation: best response / exploitability on the device ----
+ * rbl_solver_set_strategy: overwrite lane's sigma with a dense [N][H][A] strategy (rows for both players);
+ * rbl_solver_best_response: BRSolver::compute_br (subgame_solving.cc:316-358) of `traverser` against every lane's
+ *   sigma, out[B][H] = root values; pseudo-leaves (depth-limited trees) are valued by the engine's net;
+ * rbl_exploitability2: compute_exploitability2 (subgame_solving.cc:802-816) of a full-tree strategy [N_full][H][A]. */
+int rbl_solver_set_strategy(rbl_engine* e, int lane, const double* strategy);
+int rbl_solver_best_response(rbl_engine* e, int traverser, double* out);
+int rbl_exploitability2(int device, int dice, int faces, const double* strategy, double out[2]);
+/* compute_strategy_recursive (to_leaf = 0) / compute_strategy_recursive_to_leaf (1) (recursive_solving.cc:277-299) with
+ * the engine's params and net: out = dense full-tree strategy [N_full][H][A], N_full = rbl_unroll_tree(.., -1, 0, 1<<20).
+ * The frontier is solved level by level, all subgames of a level as lanes of one launch sequence. */
+int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out);
 int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out); /* get_hand_values :694-696 */
 /* update_value_network (:672-676): writes the lane's two training examples, queries[2][Q], values[2][H] */
 int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values);

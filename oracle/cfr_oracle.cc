@@ -736,6 +736,91 @@ void orc_rl_run(int dice, int faces, double random_action_prob, int sample_leaf,
   for (int i = 0; i < num_games; ++i) r.play_one_game();
 }
 
+// compute_strategy_recursive / _to_leaf (recursive_solving.cc:47-134): depth-first like the reference (the order does not
+// change the result: every subgame depends only on the beliefs handed down to it).
+namespace {
+struct Recursive {
+  Rules g;
+  orc_params sp;
+  Net net;
+  std::vector<Node> full;
+  double* out;
+  int H, A;
+  Recursive(const Rules& r, const orc_params& p, const Net& n, double* o)
+      : g(r), sp(p), net(n), full(unroll(r, -1, 0, 1000000)), out(o), H(r.H), A(r.A) {}
+  void copy_row(int full_node, const std::vector<double>& dense, int partial_node) {
+    std::copy(dense.begin() + (size_t)partial_node * H * A, dense.begin() + (size_t)(partial_node + 1) * H * A,
+              out + (size_t)full_node * H * A);
+  }
+  void per_node(int node, const std::vector<double> b[2]) {  // :47-74
+    const Node& nd = full[node];
+    if (nd.last_bid == g.liar) return;
+    Solver* s = build(g, nd.last_bid, nd.player, b[0].data(), b[1].data(), sp, net, true);
+    s->multistep();
+    copy_row(node, s->average(), 0);
+    delete s;
+    int lo, hi;
+    g.bid_range(nd.last_bid, &lo, &hi);
+    for (int c = nd.cb; c < nd.ce; ++c) {
+      std::vector<double> nb[2] = {b[0], b[1]};
+      const int action = c - nd.cb + lo;
+      for (int h = 0; h < H; ++h) nb[nd.player][h] *= out[((size_t)node * H + h) * A + action];
+      normalize_safe(nb[nd.player].data(), H, kEps, nb[nd.player].data());
+      per_node(c, nb);
+    }
+  }
+  void to_leaf(int node, const std::vector<double> b[2]) {  // :76-134, use_sampling_strategy = false
+    const Node& nd = full[node];
+    if (nd.last_bid == g.liar) return;
+    Solver* s = build(g, nd.last_bid, nd.player, b[0].data(), b[1].data(), sp, net, true);
+    s->multistep();
+    const std::vector<double> strat = s->average();
+    const std::vector<Node> part = s->trav().tree;
+    delete s;
+    struct Item {
+      int f, p;
+      std::vector<double> r[2];
+    };
+    std::vector<Item> queue;
+    queue.push_back(Item{node, 0, {b[0], b[1]}});
+    for (size_t qi = 0; qi < queue.size(); ++qi) {
+      Item it = queue[qi];
+      copy_row(it.f, strat, it.p);
+      const Node& fn = full[it.f];
+      const Node& pn = part[it.p];
+      int lo, hi;
+      g.bid_range(fn.last_bid, &lo, &hi);
+      for (int i = 0; i < pn.ce - pn.cb; ++i) {
+        Item ch{fn.cb + i, pn.cb + i, {it.r[0], it.r[1]}};
+        const int action = lo + i;
+        for (int h = 0; h < H; ++h) ch.r[fn.player][h] *= strat[((size_t)it.p * H + h) * A + action];
+        queue.push_back(ch);
+      }
+      if (pn.ce == pn.cb && fn.ce != fn.cb) {
+        normalize_safe(it.r[0].data(), H, kEps, it.r[0].data());
+        normalize_safe(it.r[1].data(), H, kEps, it.r[1].data());
+        to_leaf(it.f, it.r);
+      }
+    }
+  }
+};
+}  // namespace
+
+void orc_strategy_recursive(int dice, int faces, const orc_params* params, int to_leaf, int net_mode, orc_net_fn net_fn,
+                            void* net_user, const char* torchscript_path, double* out) {
+  (void)torchscript_path;
+  Rules g(dice, faces);
+  Recursive r(g, *params, make_net(net_mode, net_fn, net_user, nullptr, nullptr), out);
+  std::fill(out, out + r.full.size() * (size_t)g.H * g.A, 0.0);
+  std::vector<double> b[2];
+  b[0].assign(g.H, 1. / g.H);
+  b[1].assign(g.H, 1. / g.H);
+  if (to_leaf)
+    r.to_leaf(0, b);
+  else
+    r.per_node(0, b);
+}
+
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]) {
   // compute_exploitability2, subgame_solving.cc:802-816: two full-tree best-response sweeps against uniform beliefs.
   Rules g(dice, faces);

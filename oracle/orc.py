@@ -94,6 +94,9 @@ class Oracle:
         L.orc_rl_run.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int,
                                  NET_FN, C.c_void_p, C.c_char_p, EX_FN, C.c_void_p]
         L.orc_rl_run.restype = None
+        L.orc_strategy_recursive.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, NET_FN, C.c_void_p,
+                                             C.c_char_p, C.POINTER(C.c_double)]
+        L.orc_strategy_recursive.restype = None
         L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                                         C.c_int]
         L.orc_synthetic_net.restype = None
@@ -152,6 +155,16 @@ class Oracle:
         q = np.ascontiguousarray(queries, np.float32)
         out = np.zeros((q.shape[0], num_hands), np.float32)
         self.lib.orc_synthetic_net(_fp(q), q.shape[0], q.shape[1], _fp(out), num_hands, num_actions)
+        return out
+
+    def strategy_recursive(self, d, f, params, to_leaf=False, net=NET_ZERO, net_fn=None, torchscript_path=None):
+        """Full-tree strategy by recursive subgame solving (recursive_solving.cc:277-299) -> dense [N_full][H][A]."""
+        H, A = self.num_hands(d, f), self.num_actions(d, f)
+        n = len(self.unroll_tree(d, f, -1, 0, 1000000))
+        out = np.zeros((n, H, A))
+        cb = _wrap_net(net_fn, H) if net_fn is not None else NET_FN()
+        self.lib.orc_strategy_recursive(d, f, C.byref(params), int(to_leaf), net, cb, None,
+                                        (torchscript_path or "").encode(), _dp(out))
         return out
 
     def exploitability2(self, d, f, strategy):

@@ -65,6 +65,11 @@ void orc_rl_run(int dice, int faces, double random_action_prob, int sample_leaf,
                 int num_games, int net_mode, orc_net_fn net_fn, void* net_user, const char* torchscript_path,
                 orc_example_fn ex_fn, void* ex_user);
 
+/* ---- full-tree strategy by recursive subgame solving (recursive_solving.cc:47-134, 277-299): out dense [N_full][H][A];
+ *      to_leaf = 0: compute_strategy_recursive, 1: compute_strategy_recursive_to_leaf ---- */
+void orc_strategy_recursive(int dice, int faces, const orc_params* params, int to_leaf, int net_mode, orc_net_fn net_fn,
+                            void* net_user, const char* torchscript_path, double* out);
+
 /* ---- full-tree evaluation (subgame_solving.cc:802-816): strategy dense [N_full][H][A] ---- */
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]);
 

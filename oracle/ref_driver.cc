@@ -247,6 +247,19 @@ void orc_rl_run(int dice, int faces, double random_action_prob, int sample_leaf,
   for (int g = 0; g < num_games; ++g) runner.step();
 }
 
+void orc_strategy_recursive(int dice, int faces, const orc_params* params, int to_leaf, int net_mode, orc_net_fn net_fn,
+                            void* net_user, const char* torchscript_path, double* out) {
+  Game game(dice, faces);
+  auto net = make_net(game, net_mode, net_fn, net_user, torchscript_path, nullptr, nullptr);
+  const auto sp = to_params(params);
+  const TreeStrategy s = to_leaf ? compute_strategy_recursive_to_leaf(game, sp, net)
+                                 : compute_strategy_recursive(game, sp, net);
+  const int H = game.num_hands(), A = game.num_actions();
+  for (size_t n = 0; n < s.size(); ++n)
+    for (int h = 0; h < H; ++h)
+      for (int a = 0; a < A; ++a) out[(n * H + h) * A + a] = s[n].empty() ? 0.0 : s[n][h][a];
+}
+
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]) {
   Game game(dice, faces);
   const auto tree = unroll_tree(game);

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_strategy_recursive", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_engine_timing", "rbl_engine_stats",
 ]
@@ -98,6 +98,10 @@ def lib():
         "rbl_solver_total_rows": (C.c_int64, [vp]),
         "rbl_solver_get": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_get_snapshot": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_solver_set_strategy": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_solver_best_response": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_exploitability2": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
+        "rbl_strategy_recursive": (C.c_int, [vp, C.c_int, dp]),
         "rbl_solver_hand_values": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_examples": (C.c_int, [vp, C.c_int, fp, fp]),
         "rbl_solver_get_queries": (C.c_int, [vp, fp]),
@@ -146,6 +150,14 @@ def unroll_tree(d, f, root_last_bid=-1, root_player=0, max_depth=2):
     n = L.rbl_unroll_tree(d, f, root_last_bid, root_player, max_depth, None, 0)
     out = np.zeros((n, 6), np.int32)
     L.rbl_unroll_tree(d, f, root_last_bid, root_player, max_depth, _p(out, C.c_int32), n)
+    return out
+
+
+def exploitability2(dice, faces, strategy, device=0):
+    """compute_exploitability2 (subgame_solving.cc:802-816) of a dense full-tree strategy, on the GPU."""
+    s = np.ascontiguousarray(strategy, np.float64)
+    out = np.zeros(2)
+    _check(lib().rbl_exploitability2(device, dice, faces, _p(s, C.c_double), _p(out, C.c_double)))
     return out
 
 
@@ -258,6 +270,23 @@ class Engine:
     def get_snapshot(self, lane):
         out = np.zeros((self.tree_size(lane), self.H, self.A))
         _check(self.L.rbl_solver_get_snapshot(self.h, lane, _p(out, C.c_double)))
+        return out
+
+    def set_strategy(self, lane, dense):
+        d = np.ascontiguousarray(dense, np.float64)
+        assert d.shape == (self.tree_size(lane), self.H, self.A), d.shape
+        _check(self.L.rbl_solver_set_strategy(self.h, lane, _p(d, C.c_double)))
+
+    def best_response(self, traverser):
+        out = np.zeros((self.B, self.H))
+        _check(self.L.rbl_solver_best_response(self.h, traverser, _p(out, C.c_double)))
+        return out
+
+    def strategy_recursive(self, to_leaf=False):
+        """compute_strategy_recursive(_to_leaf) with this engine's params and net -> dense [N_full][H][A]."""
+        n = len(unroll_tree(self.dice, self.faces, -1, 0, 1000000))
+        out = np.zeros((n, self.H, self.A))
+        _check(self.L.rbl_strategy_recursive(self.h, int(to_leaf), _p(out, C.c_double)))
         return out
 
     def hand_values(self, lane, player):

@@ -12,6 +12,7 @@ enum CfrMode : int {
   kModeInit = 0,     // build_solver: uniform sigma, zero regrets, reach-weighted sum; then write queries
   kModeStep = 1,     // consume leaf values of the pending queries, CFR::step, then write the next queries
   kModeQueries = 2,  // only (re)write queries for `next_trav` from the current sigma
+  kModeBestResponse = 3,  // BRSolver::compute_br (subgame_solving.cc:316-358) against sigma; root values -> br_out
 };
 
 // Everything the kernel needs; passed by value (fits the kernarg segment).
@@ -52,6 +53,7 @@ struct CfrArgs {
   int mode, trav, next_trav, steps_after;
   double alpha;            // root-mean step size (subgame_solving.cc:580-590)
   double pos, neg, strat;  // discounts (:592-617)
+  double* br_out;          // [B][H] best-response root values (kModeBestResponse)
   long long* dbg;          // optional [B][16] phase timestamps (s_memtime) written by thread 0; null in production
 };
 

@@ -134,9 +134,10 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     int* t_parent = it, *t_act = it + N, *t_cb = it + 2 * N, *t_ce = it + 3 * N, *t_depth = it + 4 * N;
     int* t_leaves = it + 5 * N, *t_terms = t_leaves + v.L;
     int8_t* t_match = reinterpret_cast<int8_t*>(t_terms + v.T);
+    const bool br = a.mode == kModeBestResponse;
     const bool step = a.mode == kModeStep, load_sig = a.mode != kModeInit;
     const float* gv = a.values + (size_t)row_off * H;
-    const int n_lv = (step && a.use_lds) ? v.L * H : 0, n_mt = a.use_lds ? a.faces * H : 0, n_tab = a.use_lds ? N : 0;
+    const int n_lv = ((step || br) && a.use_lds) ? v.L * H : 0, n_mt = a.use_lds ? a.faces * H : 0, n_tab = a.use_lds ? N : 0;
     const int n_all = max(max(load_sig ? EH : 0, n_tab), max(n_lv, n_mt));
     for (int i = threadIdx.x; i < n_all; i += blockDim.x) {
       if (load_sig && i < EH) {
@@ -205,7 +206,8 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       }
   }
 
-  if (a.mode == kModeStep) {
+  if (a.mode == kModeStep || a.mode == kModeBestResponse) {
+    const bool br = a.mode == kModeBestResponse;
     const int t = a.trav;
     double* rho_t = t == 0 ? rho0 : rho1;
     const double* rho_o = t == 0 ? rho1 : rho0;
@@ -275,7 +277,14 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
           if (c0 == c1) continue;
           const double* vc = val + c0 * H + h;
           double x = 0.0;
-          if (mine) {
+          if (mine && br) {  // best response: first child, then strictly-greater children (subgame_solving.cc:336-344)
+            const int cnt = c1 - c0;
+            x = vc[0];
+            for (int k = 1; k < cnt; ++k) {
+              const double y = vc[k * H];
+              if (y > x) x = y;
+            }
+          } else if (mine) {
             const double* sc = sig + (c0 - 1) * H + h;
             double* rc = reg + (c0 - 1) * H + h;
             const int cnt = c1 - c0;
@@ -302,6 +311,10 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     }
 
     RBL_STAMP();  // 5: bottom-up
+    if (br) {
+      for (int h = threadIdx.x; h < H; h += blockDim.x) a.br_out[(size_t)lane * H + h] = val[h];
+      return;
+    }
     // -------------------------------------------------------------- running mean of the root values (:579-590)
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
       double m = rmean[t * H + h];

@@ -80,6 +80,8 @@ class Engine {
   int64_t total_rows() const { return rows_; }
   void get(int lane, int which, double* out);
   void get_snapshot(int lane, double* out);
+  void set_strategy(int lane, const double* dense);
+  void best_response(int traverser, double* out);
   void hand_values(int lane, int player, double* out);
   void examples(int lane, float* queries, float* values);
   void get_queries(float* out);
@@ -130,6 +132,7 @@ class Engine {
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
   DevBuf<long long> d_dbg_, d_ndbg_;
+  DevBuf<double> d_br_;
   DevBuf<float> d_queries_, d_values_, d_mlp_blob_, d_tmp_q_, d_tmp_o_;
 
   std::vector<int> h_shape_, h_player_, h_row_, h_act_, h_bid_;

@@ -47,6 +47,20 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
 
+  {  // full trees grow as 2^A: refuse what cannot be tabulated (2 dice x 6 faces full tree = 33.5 M nodes per shape)
+    double est = 0;
+    const int dmax = std::min(p_.max_depth, g_.A);
+    double level = 1;
+    for (int d = 0; d <= dmax; ++d) {
+      est += level;
+      level *= std::max(1, g_.A - 1 - d);
+      if (est > 5e6) break;
+    }
+    const double full = std::ldexp(1.0, g_.A);
+    if (std::min(est, full) > 4e6)
+      throw std::runtime_error("engine: tree of depth " + std::to_string(p_.max_depth) + " is too large to tabulate (" +
+                               std::to_string((long long)std::min(est, full)) + "+ nodes)");
+  }
   tabs_ = ShapeTables::build(g_, p_.max_depth);
   nmax_ = tabs_.max_N;
   emax_ = std::max(1, nmax_ - 1);
@@ -388,6 +402,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.pos = pos;
   a.neg = neg;
   a.strat = strat;
+  a.br_out = d_br_.p;
   a.dbg = d_dbg_.p && env_int("RBL_CFR_DBG", 0) ? d_dbg_.p : nullptr;
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
@@ -557,6 +572,39 @@ void Engine::get(int lane, int which, double* out) {
   }
 }
 
+// dense [N][H][A] -> the lane's edge-indexed sigma (for best-response / exploitability evaluation of a given strategy)
+void Engine::set_strategy(int lane, const double* dense) {
+  check_lane(lane);
+  sync();
+  const ShapeDev& s = tabs_.shapes[h_shape_[lane]];
+  const int H = g_.H, A = g_.A;
+  std::vector<double> edge((size_t)emax_ * H, 0.0);
+  for (int n = 1; n < s.N; ++n) {
+    const int p = tabs_.parent[s.node_off + n], a = tabs_.act[s.node_off + n];
+    for (int h = 0; h < H; ++h) edge[(size_t)(n - 1) * H + h] = dense[((size_t)p * H + h) * A + a];
+  }
+  RBL_HIP_CHECK(hipMemcpyAsync(d_sigma_.p + (size_t)lane * emax_ * H, edge.data(), edge.size() * sizeof(double),
+                               hipMemcpyHostToDevice, stream_));
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  pending_trav_ = -1;  // the queries on the device no longer match sigma
+}
+
+// BRSolver::compute_br (subgame_solving.cc:316-358) for every lane against its current sigma; out [B][H] root values
+void Engine::best_response(int traverser, double* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (B_ == 0) throw std::runtime_error("best_response: no lanes (call reset first)");
+  if (traverser != 0 && traverser != 1) throw std::runtime_error("best_response: traverser must be 0 or 1");
+  if (d_br_.n < (size_t)max_lanes_ * g_.H) d_br_.alloc((size_t)max_lanes_ * g_.H);
+  if (rows_ > 0) {  // depth-limited tree: leaf values come from the net, for this traverser and this sigma
+    launch(kModeQueries, 0, traverser, 0, 0, 1, 1, 1);
+    pending_trav_ = traverser;
+    run_net();
+  }
+  launch(kModeBestResponse, traverser, -1, 0, 0, 1, 1, 1);
+  sync();
+  RBL_HIP_CHECK(hipMemcpy(out, d_br_.p, (size_t)B_ * g_.H * sizeof(double), hipMemcpyDeviceToHost));
+}
+
 void Engine::get_snapshot(int lane, double* out) {
   check_lane(lane);
   if (!has_act_) throw std::runtime_error("get_snapshot: reset was called without act_iteration");
@@ -634,6 +682,91 @@ void Engine::read_snapshots(std::vector<double>* snap, std::vector<double>* root
   RBL_HIP_CHECK(hipMemcpyAsync(root_mean->data(), d_root_mean_.p, root_mean->size() * sizeof(double),
                                hipMemcpyDeviceToHost, stream_));
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+// =================================================================================================== evaluation
+// Full-tree strategy by recursive subgame solving (compute_strategy_recursive / _to_leaf, recursive_solving.cc:47-134,
+// 277-299).  The reference recurses depth-first, one subgame at a time; a subgame depends only on the beliefs handed
+// down to it, so here the frontier is solved level by level with every subgame of a level as one lane of the engine.
+void strategy_recursive(Engine& e, bool to_leaf, double* out) {
+  const Rules& g = e.rules();
+  const ShapeTables& tb = e.tables();
+  const int H = g.H, A = g.A;
+  const std::vector<Node> full = unroll_tree(g, -1, 0, 1000000);
+  std::fill(out, out + full.size() * (size_t)H * A, 0.0);
+  struct Item {
+    int node;
+    std::vector<double> b;  // [2][H]
+  };
+  std::vector<Item> frontier;
+  frontier.push_back(Item{0, std::vector<double>(2 * (size_t)H, 1.0 / H)});  // get_initial_beliefs
+  std::vector<double> dense;
+  while (!frontier.empty()) {
+    std::vector<Item> next;
+    for (size_t base = 0; base < frontier.size(); base += e.max_lanes()) {
+      const int B = (int)std::min<size_t>(e.max_lanes(), frontier.size() - base);
+      std::vector<int32_t> bid(B), pl(B);
+      std::vector<double> bel((size_t)B * 2 * H);
+      for (int i = 0; i < B; ++i) {
+        const Item& it = frontier[base + i];
+        bid[i] = full[it.node].last_bid;
+        pl[i] = full[it.node].player;
+        std::copy(it.b.begin(), it.b.end(), bel.begin() + (size_t)i * 2 * H);
+      }
+      e.reset(B, bid.data(), pl.data(), bel.data(), nullptr);
+      e.multistep(-1);
+      for (int i = 0; i < B; ++i) {
+        const Item& it = frontier[base + i];
+        const ShapeDev& sh = tb.shapes[bid[i] + 1];
+        dense.resize((size_t)sh.N * H * A);
+        e.get(i, RBL_GET_AVERAGE, dense.data());
+        if (!to_leaf) {  // :47-74: keep the root row, hand Bayes-updated beliefs to every child
+          const Node& nd = full[it.node];
+          std::copy(dense.begin(), dense.begin() + (size_t)H * A, out + (size_t)it.node * H * A);
+          int lo, hi;
+          g.bid_range(nd.last_bid, &lo, &hi);
+          for (int c = nd.cb; c < nd.ce; ++c) {
+            if (full[c].last_bid == g.liar) continue;
+            Item ch{c, it.b};
+            const int action = c - nd.cb + lo;
+            double* nb = ch.b.data() + (size_t)nd.player * H;
+            for (int h = 0; h < H; ++h) nb[h] *= dense[(size_t)h * A + action];
+            normalize_safe(nb, H, kEps, nb);
+            next.push_back(std::move(ch));
+          }
+        } else {  // :76-134 (use_sampling_strategy = false): copy the whole partial tree, recurse at its open leaves
+          struct Q {
+            int f, p;
+            std::vector<double> r;
+          };
+          std::vector<Q> queue;
+          queue.push_back(Q{it.node, 0, it.b});
+          for (size_t qi = 0; qi < queue.size(); ++qi) {
+            Q cur = queue[qi];
+            std::copy(dense.begin() + (size_t)cur.p * H * A, dense.begin() + (size_t)(cur.p + 1) * H * A,
+                      out + (size_t)cur.f * H * A);
+            const Node& fn = full[cur.f];
+            const int pc0 = tb.cb[sh.node_off + cur.p], pc1 = tb.ce[sh.node_off + cur.p];
+            int lo, hi;
+            g.bid_range(fn.last_bid, &lo, &hi);
+            for (int k = 0; k < pc1 - pc0; ++k) {
+              Q ch{fn.cb + k, pc0 + k, cur.r};
+              double* r = ch.r.data() + (size_t)fn.player * H;
+              for (int h = 0; h < H; ++h) r[h] *= dense[((size_t)cur.p * H + h) * A + lo + k];
+              queue.push_back(std::move(ch));
+            }
+            if (pc0 == pc1 && fn.cb != fn.ce) {
+              Item nr{cur.f, cur.r};
+              normalize_safe(nr.b.data(), H, kEps, nr.b.data());
+              normalize_safe(nr.b.data() + H, H, kEps, nr.b.data() + H);
+              next.push_back(std::move(nr));
+            }
+          }
+        }
+      }
+    }
+    frontier.swap(next);
+  }
 }
 
 // =================================================================================================== SelfPlay
@@ -891,6 +1024,35 @@ int rbl_solver_tree_size(rbl_engine* e, int lane) {
 int64_t rbl_solver_total_rows(rbl_engine* e) { return e->impl.total_rows(); }
 int rbl_solver_get(rbl_engine* e, int lane, int which, double* out) {
   return guard([&] { e->impl.get(lane, which, out); });
+}
+int rbl_solver_set_strategy(rbl_engine* e, int lane, const double* strategy) {
+  return guard([&] { e->impl.set_strategy(lane, strategy); });
+}
+int rbl_solver_best_response(rbl_engine* e, int traverser, double* out) {
+  return guard([&] { e->impl.best_response(traverser, out); });
+}
+int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out) {
+  return guard([&] { rbl::strategy_recursive(e->impl, to_leaf != 0, out); });
+}
+int rbl_exploitability2(int device, int dice, int faces, const double* strategy, double out[2]) {
+  return guard([&] {  // compute_exploitability2 (subgame_solving.cc:802-816): two full-tree BR sweeps, uniform beliefs
+    rbl_params p{};
+    p.num_iters = 1;
+    p.max_depth = 1000000;
+    p.use_cfr = 1;
+    rbl::Engine e(device, dice, faces, p, 1);
+    const int H = e.rules().H;
+    std::vector<double> b(2 * H, 1. / H), v(H);
+    const int32_t rb = -1, rp = 0;
+    e.reset(1, &rb, &rp, b.data(), nullptr);
+    e.set_strategy(0, strategy);
+    for (int t = 0; t < 2; ++t) {
+      e.best_response(t, v.data());
+      double s = 0;
+      for (int h = 0; h < H; ++h) s += v[h];  // vector_sum (util.h:87-90)
+      out[t] = s / H;
+    }
+  });
 }
 int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out) {
   return guard([&] { e->impl.get_snapshot(lane, out); });

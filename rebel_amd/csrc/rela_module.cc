@@ -17,6 +17,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 #include <torch/extension.h>
+#include <torch/script.h>
 
 #include <atomic>
 #include <chrono>
@@ -425,11 +426,24 @@ std::vector<float> to_floats(const py::handle& t) {
   return std::vector<float>(x.data_ptr<float>(), x.data_ptr<float>() + x.numel());
 }
 
+std::vector<float> to_floats(const torch::Tensor& t) {
+  auto x = t.detach().to(torch::kCPU, torch::kFloat32).contiguous();
+  return std::vector<float>(x.data_ptr<float>(), x.data_ptr<float>() + x.numel());
+}
+
 // Net2 state_dict contract (cfvpy/models.py:20-53,64-94): Linear at body.{4l}, LayerNorm at body.{4l+1}, `output`.
+bool parse_net2_map(const std::map<std::string, torch::Tensor>& sd, MlpHost* out, std::string* why);
+
 bool parse_net2(const py::object& model, MlpHost* out, std::string* why) {
-  py::dict sd = model.attr("state_dict")();
-  auto has = [&](const std::string& k) { return sd.contains(py::str(k)); };
-  auto shape = [&](const std::string& k) { return py::cast<torch::Tensor>(sd[py::str(k)]).sizes().vec(); };
+  py::dict d = model.attr("state_dict")();
+  std::map<std::string, torch::Tensor> sd;
+  for (auto item : d) sd[py::cast<std::string>(item.first)] = py::cast<torch::Tensor>(item.second);
+  return parse_net2_map(sd, out, why);
+}
+
+bool parse_net2_map(const std::map<std::string, torch::Tensor>& sd, MlpHost* out, std::string* why) {
+  auto has = [&](const std::string& k) { return sd.count(k) > 0; };
+  auto shape = [&](const std::string& k) { return sd.at(k).sizes().vec(); };
   if (!has("output.weight") || !has("output.bias")) {
     *why = "no output.weight/output.bias";
     return false;
@@ -451,13 +465,13 @@ bool parse_net2(const py::object& model, MlpHost* out, std::string* why) {
       *why = "hidden layers of different widths";
       return false;
     }
-    m.w.push_back(to_floats(sd[py::str(k + ".weight")]));
-    m.b.push_back(to_floats(sd[py::str(k + ".bias")]));
+    m.w.push_back(to_floats(sd.at(k + ".weight")));
+    m.b.push_back(to_floats(sd.at(k + ".bias")));
     consumed += 2;
     const std::string n = "body." + std::to_string(4 * l + 1);
     if (has(n + ".weight")) {
-      m.ln_w.push_back(to_floats(sd[py::str(n + ".weight")]));
-      m.ln_b.push_back(to_floats(sd[py::str(n + ".bias")]));
+      m.ln_w.push_back(to_floats(sd.at(n + ".weight")));
+      m.ln_b.push_back(to_floats(sd.at(n + ".bias")));
       consumed += 2;
     }
     ++m.n_layers;
@@ -481,8 +495,8 @@ bool parse_net2(const py::object& model, MlpHost* out, std::string* why) {
     return false;
   }
   m.n_out = (int)so[0];
-  m.w_out = to_floats(sd[py::str("output.weight")]);
-  m.b_out = to_floats(sd[py::str("output.bias")]);
+  m.w_out = to_floats(sd.at("output.weight"));
+  m.b_out = to_floats(sd.at("output.bias"));
   *out = std::move(m);
   return true;
 }
@@ -493,6 +507,32 @@ int parse_device(const std::string& device) {
          "' -- this module generates on an MI355X only (no CPU path); pass 'cuda:N' (cfg: selfplay.cpu_gen_threads=0)");
   const auto c = device.find(':');
   return c == std::string::npos ? 0 : std::atoi(device.c_str() + c + 1);
+}
+
+int apply_mlp(rbl_engine* e, const MlpHost& mlp) {
+  std::vector<const float*> w, b, g, o;
+  for (int l = 0; l < mlp.n_layers; ++l) {
+    w.push_back(mlp.w[l].data());
+    b.push_back(mlp.b[l].data());
+    if (mlp.use_ln) {
+      g.push_back(mlp.ln_w[l].data());
+      o.push_back(mlp.ln_b[l].data());
+    }
+  }
+  rbl_mlp_weights c{};
+  c.n_layers = mlp.n_layers;
+  c.n_in = mlp.n_in;
+  c.n_hidden = mlp.n_hidden;
+  c.n_out = mlp.n_out;
+  c.use_layer_norm = mlp.use_ln;
+  c.w = w.data();
+  c.b = b.data();
+  c.ln_w = mlp.use_ln ? g.data() : nullptr;
+  c.ln_b = mlp.use_ln ? o.data() : nullptr;
+  c.w_out = mlp.w_out.data();
+  c.b_out = mlp.b_out.data();
+  c.ln_eps = 1e-5f;
+  return rbl_engine_set_net_mlp(e, &c);
 }
 
 class ModelLocker {
@@ -557,29 +597,7 @@ class ModelLocker {
 
   void apply(rbl_engine* e) {  // m_ held
     if (is_mlp_) {
-      std::vector<const float*> w, b, g, o;
-      for (int l = 0; l < mlp_.n_layers; ++l) {
-        w.push_back(mlp_.w[l].data());
-        b.push_back(mlp_.b[l].data());
-        if (mlp_.use_ln) {
-          g.push_back(mlp_.ln_w[l].data());
-          o.push_back(mlp_.ln_b[l].data());
-        }
-      }
-      rbl_mlp_weights c{};
-      c.n_layers = mlp_.n_layers;
-      c.n_in = mlp_.n_in;
-      c.n_hidden = mlp_.n_hidden;
-      c.n_out = mlp_.n_out;
-      c.use_layer_norm = mlp_.use_ln;
-      c.w = w.data();
-      c.b = b.data();
-      c.ln_w = mlp_.use_ln ? g.data() : nullptr;
-      c.ln_b = mlp_.use_ln ? o.data() : nullptr;
-      c.w_out = mlp_.w_out.data();
-      c.b_out = mlp_.b_out.data();
-      c.ln_eps = 1e-5f;
-      if (rbl_engine_set_net_mlp(e, &c) == 0) return;
+      if (apply_mlp(e, mlp_) == 0) return;
       // shape outside the fused kernel's envelope (e.g. n_hidden=512): fall through to the TorchScript forward
       jit_ = py_models_[0].attr("_c").cast<torch::jit::Module*>();
     }
@@ -759,10 +777,90 @@ class Context {  // rela/context.h:26-85
   std::vector<std::unique_ptr<Worker>> workers_;
 };
 
-[[noreturn]] void eval_not_built(const char* name) {
-  fail(std::string("rebel_amd.rela.") + name +
-       ": full-tree evaluation (best-response / exploitability sweep) is not part of the MI355X data-generation path "
-       "yet (DESIGN.md, 'next' rows); use the reference build for evaluation");
+// ---- evaluation helpers (rela/pybind.cc:45-105) on the device: level-batched recursive solving + BR sweeps
+int eval_device() {
+  const char* d = std::getenv("REBEL_AMD_EVAL_DEVICE");
+  return d && *d ? std::atoi(d) : 0;
+}
+
+struct EvalEngine {
+  rbl_engine* e = nullptr;
+  EvalEngine(const RecursiveSolvingParams& params, const SubgameSolvingParams& sp, int lanes) {
+    const rbl_params p = to_c(sp);
+    e = rbl_engine_create(eval_device(), params.num_dice, params.num_faces, &p, lanes);
+    if (!e) fail(rbl_last_error());
+  }
+  ~EvalEngine() {
+    if (e) rbl_engine_destroy(e);
+  }
+};
+
+void load_torchscript_net(rbl_engine* e, const std::string& model_path) {  // create_torchscript_net, real_net.cc:57-87
+  torch::jit::Module module = torch::jit::load(model_path, torch::kCPU);
+  std::map<std::string, torch::Tensor> sd;
+  for (const auto& p : module.named_parameters()) sd[p.name] = p.value;
+  MlpHost mlp;
+  std::string why;
+  if (!parse_net2_map(sd, &mlp, &why)) fail("model at " + model_path + " is not a Net2-shaped MLP: " + why);
+  if (apply_mlp(e, mlp) != 0) fail(rbl_last_error());
+}
+
+int full_tree_size(const RecursiveSolvingParams& params) {
+  return rbl_unroll_tree(params.num_dice, params.num_faces, -1, 0, 1000000, nullptr, 0);
+}
+
+// compute_strategy_recursive(_to_leaf) + compute_exploitability (= mean of the two BR values, subgame_solving.cc:818-821)
+float exploitability_with_net_impl(const RecursiveSolvingParams& params, const std::string& model_path, bool to_leaf) {
+  EvalEngine ev(params, params.subgame_params, 4096);
+  load_torchscript_net(ev.e, model_path);
+  const int n = full_tree_size(params);
+  const int H = rbl_num_hands(params.num_dice, params.num_faces), A = rbl_num_actions(params.num_dice, params.num_faces);
+  std::vector<double> strategy((size_t)n * H * A);
+  check(rbl_strategy_recursive(ev.e, to_leaf ? 1 : 0, strategy.data()), "strategy_recursive");
+  double ex[2];
+  check(rbl_exploitability2(eval_device(), params.num_dice, params.num_faces, strategy.data(), ex), "exploitability2");
+  return (float)((ex[0] + ex[1]) / 2.);
+}
+
+float compute_exploitability(RecursiveSolvingParams params, const std::string& model_path) {  // pybind.cc:45-55
+  py::gil_scoped_release release;
+  return exploitability_with_net_impl(params, model_path, /*to_leaf=*/false);
+}
+
+// pybind.cc:57-84.  The first element (exploitability of the to-leaf recursive strategy) is computed on the device; the
+// two net-quality MSEs come from stats.cc's eval_net, a CPU diagnostic that is out of scope here:
+// they are returned as NaN, never as made-up numbers.
+std::tuple<float, float, float> compute_stats_with_net(RecursiveSolvingParams params, const std::string& model_path) {
+  py::gil_scoped_release release;
+  const float ex = exploitability_with_net_impl(params, model_path, /*to_leaf=*/true);
+  const float nan = std::nanf("");
+  return std::make_tuple(ex, nan, nan);
+}
+
+// pybind.cc:86-105 never calls step() on its solver (so it prints the exploitability of the uniform strategy
+// num_iters times and returns 0).  Fixed knowingly: the full-tree CFR solve really runs (on the device), the
+// exploitability is printed at powers of two like the reference does, and (e0 + e1) / 2 of the final average strategy is
+// returned.
+float compute_exploitability_no_net(RecursiveSolvingParams params) {
+  py::gil_scoped_release release;
+  auto sp = params.subgame_params;
+  sp.max_depth = 1000000;
+  EvalEngine ev(params, sp, 1);
+  const int H = rbl_num_hands(params.num_dice, params.num_faces), A = rbl_num_actions(params.num_dice, params.num_faces);
+  const int n = full_tree_size(params);
+  std::vector<double> b(2 * (size_t)H, 1. / H), strategy((size_t)n * H * A);
+  const int32_t rb = -1, rp = 0;
+  check(rbl_solver_reset(ev.e, 1, &rb, &rp, b.data(), nullptr), "reset");
+  double ex[2] = {0, 0};
+  for (int iter = 0; iter < sp.num_iters; ++iter) {
+    check(rbl_solver_step(ev.e, iter % 2), "step");
+    if (((iter + 1) & iter) == 0 || iter + 1 == sp.num_iters) {
+      check(rbl_solver_get(ev.e, 0, RBL_GET_AVERAGE, strategy.data()), "get");
+      check(rbl_exploitability2(eval_device(), params.num_dice, params.num_faces, strategy.data(), ex), "exploitability2");
+      std::printf("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e\n", iter + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2.);
+    }
+  }
+  return (float)((ex[0] + ex[1]) / 2.);
 }
 
 }  // namespace
@@ -827,18 +925,9 @@ PYBIND11_MODULE(rela, m) {
       .def(py::init<std::vector<py::object>, const std::string&>())
       .def("update_model", &ModelLocker::update_model);
 
-  m.def("compute_exploitability_fp",
-        [](const RecursiveSolvingParams&) -> float { eval_not_built("compute_exploitability_fp"); }, py::arg("params"));
-  m.def("compute_exploitability_with_net",
-        [](const RecursiveSolvingParams&, const std::string&) -> float {
-          eval_not_built("compute_exploitability_with_net");
-        },
-        py::arg("params"), py::arg("model_path"));
-  m.def("compute_stats_with_net",
-        [](const RecursiveSolvingParams&, const std::string&) -> std::tuple<float, float, float> {
-          eval_not_built("compute_stats_with_net");
-        },
-        py::arg("params"), py::arg("model_path"));
+  m.def("compute_exploitability_fp", &compute_exploitability_no_net, py::arg("params"));
+  m.def("compute_exploitability_with_net", &compute_exploitability, py::arg("params"), py::arg("model_path"));
+  m.def("compute_stats_with_net", &compute_stats_with_net, py::arg("params"), py::arg("model_path"));
 
   m.def("create_cfr_thread", &create_cfr_thread, py::arg("model_locker"), py::arg("replay"), py::arg("cfg"),
         py::arg("seed"));

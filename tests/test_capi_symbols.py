@@ -66,7 +66,7 @@ def test_compute_fails_loudly_without_device():
 
 def test_product_never_touches_the_oracle():
     """No import / include / link / dlopen of anything under oracle/ from the product tree (comments may cite it)."""
-    pat = re.compile(r"(from|import)\s+oracle\b|#include\s*[\"<][^\n]*orc|liboracle|libref_driver|oracle/_|dlopen|CDLL\([^)]*orac")
+    pat = re.compile(r"(from|import)\s+oracle\b|#include\s*[\"<][^\n]*(orc_api|oracle|cfr_oracle)|liboracle|libref_driver|oracle/_|dlopen|CDLL\([^)]*orac")
     for base, _, files in os.walk(os.path.join(ROOT, "rebel_amd")):
         if "_build" in base or "__pycache__" in base:
             continue

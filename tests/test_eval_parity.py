@@ -1,0 +1,71 @@
+"""GPU parity for the evaluation row: best response / exploitability sweeps on the device against the
+oracle (BRSolver::compute_br, compute_exploitability2; subgame_solving.cc:316-358, 802-816) -- bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("d,f,iters", [(1, 4, 128), (1, 5, 40), (2, 2, 60), (1, 6, 16)])
+def test_exploitability2_bit_exact(d, f, iters, port):
+    from oracle import orc
+    from rebel_amd import capi
+
+    p = orc.make_params(num_iters=iters, max_depth=100, linear_update=True, use_cfr=True)
+    s = port.solver(d, f, p, net=orc.NET_NONE)
+    s.multistep()
+    for which in (orc.GET_AVERAGE, orc.GET_LAST):
+        strat = s.get(which)
+        assert np.array_equal(capi.exploitability2(d, f, strat), port.exploitability2(d, f, strat))
+
+
+def test_exploitability_of_gpu_solved_strategy_converges():
+    """subgame_solving_test.cc:162-179: linear CFR on 1 die x 2 faces, 180 iterations -> exploitability in [0, 1e-3),
+    with solve AND evaluation on the device."""
+    from rebel_amd import capi
+
+    e = capi.Engine(1, 2, capi.make_params(num_iters=180, max_depth=100, linear_update=True, use_cfr=True))
+    e.reset([-1], [0], np.full((1, 2, e.H), 1.0 / e.H))
+    e.multistep()
+    expl = capi.exploitability2(1, 2, e.get(0, capi.GET_AVERAGE))
+    total = (expl[0] + expl[1]) / 2
+    assert 0 <= total < 1e-3, expl
+
+
+def test_best_response_on_depth_limited_lanes(port):
+    """BR with net-valued pseudo-leaves, several lanes at once.  FP::step(t) IS compute_br(t, average strategy)
+    (subgame_solving.cc:433-476), so the oracle's first fictitious-play step yields the reference BR root values
+    against the uniform strategy a freshly reset lane holds."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=30, max_depth=2, linear_update=True, use_cfr=True)
+    e = capi.Engine(1, 6, capi.make_params(**kw), max_lanes=3)
+    e.set_net_synthetic()
+    rng = np.random.default_rng(3)
+    roots, players = [-1, 4, 9], [0, 1, 0]
+    beliefs = rng.dirichlet(np.ones(e.H), size=(3, 2))
+    e.reset(roots, players, beliefs)  # sigma = uniform after reset
+    for t in (0, 1):
+        got = e.best_response(t)
+        for b in range(3):
+            o = port.solver(1, 6, orc.make_params(num_iters=2, max_depth=2, use_cfr=False), roots[b], players[b],
+                            beliefs[b], orc.NET_SYNTHETIC)
+            o.step(t)
+            assert np.array_equal(got[b], o.hand_values(t)), (t, b)
+
+
+@pytest.mark.parametrize("to_leaf", [False, True])
+@pytest.mark.parametrize("d,f,depth,iters", [(1, 4, 2, 32), (1, 4, 3, 10), (1, 5, 2, 12), (2, 2, 2, 20)])
+def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port):
+    """compute_strategy_recursive(_to_leaf) level-batched on the device == the oracle's depth-first recursion."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=iters, max_depth=depth, linear_update=True, use_cfr=True)
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=64)  # smaller than the widest level: exercises chunking
+    e.set_net_synthetic()
+    got = e.strategy_recursive(to_leaf=to_leaf)
+    want = port.strategy_recursive(d, f, orc.make_params(**kw), to_leaf=to_leaf, net=orc.NET_SYNTHETIC)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(capi.exploitability2(d, f, got), port.exploitability2(d, f, want))

@@ -82,3 +82,15 @@ def test_exploitability_matches(port, ref):
     s.multistep()
     strat = s.get(orc.GET_AVERAGE)
     assert np.array_equal(ref.exploitability2(1, 4, strat), port.exploitability2(1, 4, strat))
+
+
+@pytest.mark.parametrize("to_leaf", [False, True])
+@pytest.mark.parametrize("d,f,depth,iters", [(1, 3, 2, 24), (1, 4, 2, 16), (1, 4, 3, 10)])
+def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port, ref):
+    """compute_strategy_recursive(_to_leaf) (recursive_solving.cc:277-299): the port's restatement vs the reference,
+    synthetic net, full-tree dense strategy bit for bit."""
+    p = orc.make_params(num_iters=iters, max_depth=depth, linear_update=True, use_cfr=True)
+    a = ref.strategy_recursive(d, f, p, to_leaf=to_leaf, net=orc.NET_SYNTHETIC)
+    o = port.strategy_recursive(d, f, p, to_leaf=to_leaf, net=orc.NET_SYNTHETIC)
+    assert a.shape == o.shape and np.array_equal(a, o)
+    assert np.array_equal(ref.exploitability2(d, f, a), port.exploitability2(d, f, o))

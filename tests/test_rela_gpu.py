@@ -159,3 +159,42 @@ def test_rela_lane_matches_capi_lane():
     _wait(ctx.terminated, 60)
     data = replay.extract()
     assert np.array_equal(data[0].numpy()[:12], want_q) and np.array_equal(data[1].numpy()[:12], want_v)
+
+
+def test_eval_helpers_against_oracle(tmp_path, port):
+    """rela.compute_exploitability_with_net / compute_stats_with_net / compute_exploitability_fp on the device vs the
+    oracle driven by the same TorchScript net evaluated by torch on CPU (P3-style: the net forward differs by ~1e-7, so
+    the comparison is to 1e-4 on exploitability after few iterations, not bit-exact)."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from oracle import orc
+    from rebel_amd.models import Net2
+
+    d, f, iters = 1, 4, 24
+    torch.manual_seed(5)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    with torch.no_grad():
+        net.output.weight *= 30
+        net.output.bias *= 30
+    path = str(tmp_path / "net.torchscript")
+    torch.jit.save(torch.jit.script(net), path)
+    cfg = _cfg(rela, d, f, iters)
+
+    def fn(q):
+        with torch.no_grad():
+            return net(torch.from_numpy(q)).numpy()
+
+    p = orc.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+    for to_leaf, got in ((False, rela.compute_exploitability_with_net(cfg, path)),
+                         (True, rela.compute_stats_with_net(cfg, path)[0])):
+        strat = port.strategy_recursive(d, f, p, to_leaf=to_leaf, net=orc.NET_CALLBACK, net_fn=fn)
+        ex = port.exploitability2(d, f, strat)
+        assert abs(got - (ex[0] + ex[1]) / 2) < 1e-4, (to_leaf, got, ex)
+    s = rela.compute_stats_with_net(cfg, path)
+    assert np.isnan(s[1]) and np.isnan(s[2])  # eval_net MSEs are out of scope: NaN, not invented numbers
+
+    # full-tree CFR solve + exploitability (the reference's compute_exploitability_fp never steps; ours does)
+    cfg2 = _cfg(rela, 1, 2, 180)
+    total = rela.compute_exploitability_fp(cfg2)
+    assert 0 <= total < 1e-3  # subgame_solving_test.cc:162-179

@@ -188,6 +188,14 @@ def test_model_locker_refuses_cpu_device(ours):
         ours.ModelLocker([m], "cpu")
 
 
-def test_eval_helpers_fail_loudly(ours):
-    with pytest.raises(RuntimeError, match="not part of"):
-        ours.compute_exploitability_fp(ours.RecursiveSolvingParams())
+def test_eval_helpers_need_a_gpu(ours):
+    """The evaluation helpers run on the device too: without one they raise, they never fall back to a CPU path."""
+    from rebel_amd import capi
+
+    if capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = ours.RecursiveSolvingParams()
+    p.num_dice, p.num_faces = 1, 3
+    p.subgame_params.use_cfr = True
+    with pytest.raises(RuntimeError, match="HIP|device"):
+        ours.compute_exploitability_fp(p)
