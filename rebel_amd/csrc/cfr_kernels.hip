@@ -75,10 +75,13 @@ __device__ __forceinline__ void sweep_reach(const LaneView& v, const double* sig
   }
 }
 
+// HT / AT: compile-time number of hands / actions for the common games (0 = read them from the arguments); with them
+// known every `* H`, `% H`, `/ Q` below is strength-reduced and the per-hand loops unroll.
+template <int HT, int AT>
 __global__ void cfr_step_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   const int lane = a.lane0 + blockIdx.x;
-  const int H = a.H, A = a.A, Q = a.Q;
+  const int H = HT > 0 ? HT : a.H, A = AT > 0 ? AT : a.A, Q = HT > 0 ? 2 + AT + 2 * HT : a.Q;
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
   LaneView v;
   v.N = sh.N;
@@ -412,7 +415,14 @@ void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out,
 }
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream) {
-  hipLaunchKernelGGL(cfr_step_kernel, dim3(B), dim3(block), a.use_lds ? lds_bytes : 0, stream, a);
+  const size_t lds = a.use_lds ? lds_bytes : 0;
+#define RBL_CFR(HT_, AT_) hipLaunchKernelGGL((cfr_step_kernel<HT_, AT_>), dim3(B), dim3(block), lds, stream, a)
+  if (a.H == 6 && a.A == 13) RBL_CFR(6, 13);        // 1 die x 6 faces
+  else if (a.H == 4 && a.A == 9) RBL_CFR(4, 9);     // 1 die x 4 faces
+  else if (a.H == 9 && a.A == 13) RBL_CFR(9, 13);   // 2 dice x 3 faces
+  else if (a.H == 5 && a.A == 11) RBL_CFR(5, 11);   // 1 die x 5 faces
+  else RBL_CFR(0, 0);
+#undef RBL_CFR
 }
 
 }  // namespace rbl

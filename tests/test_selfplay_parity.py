@@ -60,3 +60,20 @@ def test_selfplay_many_lanes_vs_oracle(port):
         assert len(ex) == len(ref), seed
         for (q, v), (rq, rv) in zip(ex, ref):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
+
+
+def test_selfplay_2d6f_global_scratch_path(port):
+    """2 dice x 6 faces (H = 36, root subgame N = 325): the lane working set does not fit LDS, so the kernel runs on its
+    per-lane global scratch slab; trajectories still equal the oracle's bit for bit."""
+    from oracle import orc
+
+    c = dict(d=2, f=6, p=dict(num_iters=12, max_depth=2, linear_update=True, use_cfr=True), rap=0.25, leaf=True,
+             net="synthetic")
+    seeds = [3, 4, 5]
+    lanes = _run_lanes(c, seeds, 2)
+    for seed, ex in zip(seeds, lanes):
+        ref = port.rl_run(c["d"], c["f"], orc.make_params(**c["p"]), seed, 2, random_action_prob=c["rap"],
+                          sample_leaf=c["leaf"], net=orc.NET_SYNTHETIC)
+        assert len(ex) == len(ref), seed
+        for (q, v), (rq, rv) in zip(ex, ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
