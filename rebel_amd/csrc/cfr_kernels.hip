@@ -77,13 +77,16 @@ __device__ __forceinline__ void sweep_reach(const LaneView& v, const double* sig
 
 // HT / AT: compile-time number of hands / actions for the common games (0 = read them from the arguments); with them
 // known every `* H`, `% H`, `/ Q` below is strength-reduced and the per-hand loops unroll.
-template <int HT, int AT>
+// LDS: compile-time choice of where the lane's working set lives.  It has to be a template parameter: with a run-time
+// `use_lds ? lds : scratch` every working-set pointer is generic and hipcc emits FLAT loads/stores with 64-bit address
+// arithmetic for what should be ds_read/ds_write (and spills SGPRs holding the pointers).
+template <int HT, int AT, bool LDS>
 __global__ void cfr_step_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   const int lane = a.lane0 + blockIdx.x;
   const int H = HT > 0 ? HT : a.H, A = AT > 0 ? AT : a.A, Q = HT > 0 ? 2 + AT + 2 * HT : a.Q;
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
-  LaneView v;
+  LaneView v;  // the tables the phases read: LDS copies when LDS, the global tables otherwise
   v.N = sh.N;
   v.L = sh.L;
   v.T = sh.T;
@@ -111,7 +114,11 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
   RBL_STAMP();  // 0: start
 
   // working set: LDS when it fits, else a per-lane slab of global scratch (big trees: 2 dice x 6 faces, full trees)
-  double* W = a.use_lds ? lds : a.scratch + (size_t)lane * a.work_stride;
+  double* W;
+  if constexpr (LDS)
+    W = lds;
+  else
+    W = a.scratch + (size_t)lane * a.work_stride;
   double* rho0 = W;
   double* rho1 = rho0 + NH;
   double* val = rho1 + NH;
@@ -140,7 +147,8 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     const bool br = a.mode == kModeBestResponse;
     const bool step = a.mode == kModeStep, load_sig = a.mode != kModeInit;
     const float* gv = a.values + (size_t)row_off * H;
-    const int n_lv = ((step || br) && a.use_lds) ? v.L * H : 0, n_mt = a.use_lds ? a.faces * H : 0, n_tab = a.use_lds ? N : 0;
+    const int n_lv = ((step || br) && LDS) ? v.L * H : 0, n_mt = LDS ? a.faces * H : 0, n_tab = LDS ? N : 0;
+    const LaneView gt = v;  // global tables (source of the staging copy)
     const int n_all = max(max(load_sig ? EH : 0, n_tab), max(n_lv, n_mt));
     for (int i = threadIdx.x; i < n_all; i += blockDim.x) {
       if (load_sig && i < EH) {
@@ -149,13 +157,13 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       }
       if (i < n_lv) lvals[i] = gv[i];
       if (i < n_tab) {
-        t_parent[i] = v.parent[i];
-        t_act[i] = v.act[i];
-        t_cb[i] = v.cb[i];
-        t_ce[i] = v.ce[i];
-        t_depth[i] = v.depth[i];
-        if (i < v.L) t_leaves[i] = v.leaves[i];
-        if (i < v.T) t_terms[i] = v.terms[i];
+        t_parent[i] = gt.parent[i];
+        t_act[i] = gt.act[i];
+        t_cb[i] = gt.cb[i];
+        t_ce[i] = gt.ce[i];
+        t_depth[i] = gt.depth[i];
+        if (i < v.L) t_leaves[i] = gt.leaves[i];
+        if (i < v.T) t_terms[i] = gt.terms[i];
       }
       if (i < n_mt) t_match[i] = a.matches[i];
     }
@@ -164,7 +172,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       rho1[i] = bel[H + i];
     }
     __syncthreads();
-    if (a.use_lds) {
+    if constexpr (LDS) {
       v.parent = t_parent;
       v.act = t_act;
       v.cb = t_cb;
@@ -249,7 +257,11 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       const int h = gh.col;
       for (int k = gh.row0; k < v.L + v.T; k += gh.rpp) {
         if (k < v.L) {  // leaf_values(float) *= scalers(double), stored back as float (:268), read as double (:275)
-          const float x = a.use_lds ? lvals[k * H + h] : a.values[(size_t)(row_off + k) * H + h];
+          float x;
+          if constexpr (LDS)
+            x = lvals[k * H + h];
+          else
+            x = a.values[(size_t)(row_off + k) * H + h];
           val[v.leaves[k] * H + h] = (double)(float)((double)x * lscale[k]);
         } else {  // compute_expected_terminal_values (:80-98)
           const int zi = k - v.L, z = v.terms[zi];
@@ -415,8 +427,13 @@ void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out,
 }
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream) {
-  const size_t lds = a.use_lds ? lds_bytes : 0;
-#define RBL_CFR(HT_, AT_) hipLaunchKernelGGL((cfr_step_kernel<HT_, AT_>), dim3(B), dim3(block), lds, stream, a)
+#define RBL_CFR(HT_, AT_)                                                                                         \
+  do {                                                                                                            \
+    if (a.use_lds)                                                                                                \
+      hipLaunchKernelGGL((cfr_step_kernel<HT_, AT_, true>), dim3(B), dim3(block), lds_bytes, stream, a);          \
+    else                                                                                                          \
+      hipLaunchKernelGGL((cfr_step_kernel<HT_, AT_, false>), dim3(B), dim3(block), 0, stream, a);                 \
+  } while (0)
   if (a.H == 6 && a.A == 13) RBL_CFR(6, 13);        // 1 die x 6 faces
   else if (a.H == 4 && a.A == 9) RBL_CFR(4, 9);     // 1 die x 4 faces
   else if (a.H == 9 && a.A == 13) RBL_CFR(9, 13);   // 2 dice x 3 faces
