@@ -6,7 +6,7 @@ B = 4096
 e = capi.Engine(1, 6, capi.make_params(num_iters=1024, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
 e.set_net_synthetic()
 e.reset([-1]*B, [0]*B, np.full((B, 2, e.H), 1.0/e.H))
-e.multistep(9); e.sync()
+e.multistep(int(sys.argv[1]) if len(sys.argv) > 1 else 9); e.sync()
 d = e.debug_stamps()
 names = ["staged", "reach", "leaf scalers", "leaf values", "bottom-up", "new reach", "write-back", "queries"]
 dt = np.diff(d[:, :9], axis=1)
