@@ -27,7 +27,8 @@ extern "C" {
 typedef struct rbl_engine rbl_engine;     /* one GPU, one game (dice x faces), one set of solver params */
 typedef struct rbl_selfplay rbl_selfplay; /* a set of RlRunner lanes on an engine */
 
-/* SubgameSolvingParams (subgame_solving.h:43-58).  use_cfr must be 1 (the path north_star names); FP is rejected. */
+/* SubgameSolvingParams (subgame_solving.h:43-58).  use_cfr = 1: CFR / linear CFR / DCFR (the path north_star names);
+ * use_cfr = 0: fictitious play incl. linear_update and optimistic (FP, subgame_solving.cc:364-506). */
 typedef struct {
   int32_t num_iters, max_depth, linear_update, use_cfr, optimistic, dcfr;
   double dcfr_alpha, dcfr_beta, dcfr_gamma;

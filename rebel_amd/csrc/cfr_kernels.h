@@ -13,6 +13,7 @@ enum CfrMode : int {
   kModeStep = 1,     // consume leaf values of the pending queries, CFR::step, then write the next queries
   kModeQueries = 2,  // only (re)write queries for `next_trav` from the current sigma
   kModeBestResponse = 3,  // BRSolver::compute_br (subgame_solving.cc:316-358) against sigma; root values -> br_out
+  kModeFpStep = 4,        // FP::step (subgame_solving.cc:433-476): sigma holds the AVERAGE strategy, regrets hold `last`
 };
 
 // Everything the kernel needs; passed by value (fits the kernarg segment).
@@ -52,7 +53,8 @@ struct CfrArgs {
   int lane0;  // first lane of this launch (half-batches run on separate streams)
   int mode, trav, next_trav, steps_after;
   double alpha;            // root-mean step size (subgame_solving.cc:580-590)
-  double pos, neg, strat;  // discounts (:592-617)
+  double pos, neg, strat;  // discounts (:592-617); kModeFpStep: strat = linear factor (n+1)/(n+2) or 1
+  int optimistic;          // FP only (util.h:50-60)
   double* br_out;          // [B][H] best-response root values (kModeBestResponse)
   long long* dbg;          // optional [B][16] phase timestamps (s_memtime) written by thread 0; null in production
 };

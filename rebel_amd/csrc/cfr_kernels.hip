@@ -144,7 +144,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     int* t_parent = it, *t_act = it + N, *t_cb = it + 2 * N, *t_ce = it + 3 * N, *t_depth = it + 4 * N;
     int* t_leaves = it + 5 * N, *t_terms = t_leaves + v.L;
     int8_t* t_match = reinterpret_cast<int8_t*>(t_terms + v.T);
-    const bool br = a.mode == kModeBestResponse;
+    const bool br = a.mode == kModeBestResponse || a.mode == kModeFpStep;
     const bool step = a.mode == kModeStep, load_sig = a.mode != kModeInit;
     const float* gv = a.values + (size_t)row_off * H;
     const int n_lv = ((step || br) && LDS) ? v.L * H : 0, n_mt = LDS ? a.faces * H : 0, n_tab = LDS ? N : 0;
@@ -217,8 +217,9 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       }
   }
 
-  if (a.mode == kModeStep || a.mode == kModeBestResponse) {
-    const bool br = a.mode == kModeBestResponse;
+  if (a.mode == kModeStep || a.mode == kModeBestResponse || a.mode == kModeFpStep) {
+    const bool fp = a.mode == kModeFpStep;
+    const bool br = a.mode == kModeBestResponse || fp;
     const int t = a.trav;
     double* rho_t = t == 0 ? rho0 : rho1;
     const double* rho_o = t == 0 ? rho1 : rho0;
@@ -294,11 +295,17 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
           double x = 0.0;
           if (mine && br) {  // best response: first child, then strictly-greater children (subgame_solving.cc:336-344)
             const int cnt = c1 - c0;
+            int best = 0;
             x = vc[0];
             for (int k = 1; k < cnt; ++k) {
               const double y = vc[k * H];
-              if (y > x) x = y;
+              if (y > x) {
+                x = y;
+                best = k;
+              }
             }
+            if (fp)  // br_strategies as a one-hot over the node's edges (:345-348), kept in the staged `reg` rows
+              for (int k = 0; k < cnt; ++k) reg[(c0 - 1 + k) * H + h] = k == best ? 1.0 : 0.0;
           } else if (mine) {
             const double* sc = sig + (c0 - 1) * H + h;
             double* rc = reg + (c0 - 1) * H + h;
@@ -326,10 +333,68 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     }
 
     RBL_STAMP();  // 5: bottom-up
-    if (br) {
+    if (br && !fp) {
       for (int h = threadIdx.x; h < H; h += blockDim.x) a.br_out[(size_t)lane * H + h] = val[h];
       return;
     }
+    if (fp) {
+      // ------------------------------------------------------------ fictitious play (FP::step, :433-476)
+      for (int h = threadIdx.x; h < H; h += blockDim.x) {  // root_values_means (:441-452)
+        double m = rmean[t * H + h];
+        m += (val[h] - m) * a.alpha;
+        rmean[t * H + h] = m;
+      }
+      __syncthreads();  // val[root] consumed; val is reused below for the updated sum rows
+      // update_sum_strat (:401-431): traverser's reach under its best response, top-down from the lane's beliefs
+      sweep_reach(v, reg, rho0, rho1, t, root_player, H, gh);
+      double* nsum = val;  // edge-indexed scratch: E*H <= N*H
+      if (gh.active)
+        for (int n = 1 + gh.row0; n < N; n += gh.rpp) {
+          const int p = v.parent[n], h = gh.col, i = (n - 1) * H + h;
+          if ((root_player ^ (v.depth[p] & 1)) == t) {
+            const double c = rho_t[p * H + h] * reg[i];  // traverser_beliefs * br
+            double s = g_sum[i] + c;
+            if (a.strat != 1.0) s *= a.strat;  // linear_update: sum *= (n+1)/(n+2) (:459-461)
+            nsum[i] = s;
+            reg[i] = c;  // last_strategies
+          }
+        }
+      __syncthreads();
+      {  // normalise rows of the traverser's nodes (:456-472); row sums sequential over the actions
+        const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after;
+        double* snap = a.snapshot + lane_e;
+        if (gh.active) {
+          const int h = gh.col;
+          for (int n = gh.row0; n < N; n += gh.rpp) {
+            const int c0 = v.cb[n], c1 = v.ce[n];
+            if (c0 == c1 || (root_player ^ (v.depth[n] & 1)) != t) continue;
+            double s = 0.0;
+            for (int c = c0; c < c1; ++c) s += nsum[(c - 1) * H + h];
+            if (a.optimistic) {
+              double sl = 0.0;
+              for (int c = c0; c < c1; ++c) sl += reg[(c - 1) * H + h];
+              s = s + sl;
+            }
+            for (int c = c0; c < c1; ++c) {
+              const int i = (c - 1) * H + h;
+              const double num = a.optimistic ? nsum[i] + reg[i] : nsum[i];
+              const double av = num / s;
+              sig[i] = av;
+              g_sig[i] = av;
+              g_sum[i] = nsum[i];
+              g_reg[i] = reg[i];
+            }
+          }
+        }
+        __syncthreads();
+        if (snap_now)
+          for (int i = threadIdx.x; i < EH; i += blockDim.x) snap[i] = sig[i];
+      }
+      // reach of the traverser under the NEW average strategy, for the next queries
+      for (int i = threadIdx.x; i < H; i += blockDim.x) (t == 0 ? rho0 : rho1)[i] = bel[t * H + i];
+      __syncthreads();
+      sweep_reach(v, sig, rho0, rho1, t, root_player, H, gh);
+    } else {
     // -------------------------------------------------------------- running mean of the root values (:579-590)
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
       double m = rmean[t * H + h];
@@ -359,6 +424,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
           if (snap_now) snap[i] = sig[i];
         }
     }
+    }  // CFR (not FP)
   }
 
   RBL_STAMP();  // 7 (3 in init/query modes): write-back

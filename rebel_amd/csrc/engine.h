@@ -140,7 +140,7 @@ class Engine {
   int B_ = 0;
   int64_t rows_ = 0;
   bool has_act_ = false;
-  int iter_ = 0, num_steps_[2] = {0, 0}, pending_trav_ = -1;
+  int iter_ = 0, num_steps_[2] = {0, 0}, pending_trav_ = -1, num_strategies_ = 0;
 
   std::mutex net_mutex_;  // weight refresh (another thread) vs the net launch inside step()
   NetMode net_mode_ = NetMode::kZero;

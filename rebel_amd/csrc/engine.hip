@@ -32,7 +32,7 @@ int env_int(const char* name, int dflt) {
 // =================================================================================================== Engine
 Engine::Engine(int device, int dice, int faces, const rbl_params& params, int max_lanes)
     : device_(device), g_(dice, faces), p_(params), max_lanes_(max_lanes) {
-  if (!p_.use_cfr) throw std::runtime_error("engine: only use_cfr=1 is implemented on the GPU path (FP solver is out of scope)");
+  if (!p_.use_cfr && p_.dcfr) throw std::runtime_error("engine: dcfr needs use_cfr=1");
   if (p_.linear_update && p_.dcfr) throw std::runtime_error("engine: linear_update and dcfr are exclusive (subgame_solving.cc:533)");
   if (p_.max_depth < 0) throw std::runtime_error("engine: max_depth must be >= 0");
   if (max_lanes < 1) throw std::runtime_error("engine: max_lanes must be >= 1");
@@ -356,6 +356,7 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   }
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
   for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
+  num_strategies_ = 0;
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
 }
@@ -402,6 +403,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.pos = pos;
   a.neg = neg;
   a.strat = strat;
+  a.optimistic = p_.optimistic ? 1 : 0;
   a.br_out = d_br_.p;
   a.dbg = d_dbg_.p && env_int("RBL_CFR_DBG", 0) ? d_dbg_.p : nullptr;
   for (int part = 0; part < n_parts_; ++part) {
@@ -414,7 +416,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     launch_cfr(a, cnt, block_, lds_bytes_, st);
     time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
-    if (mode == kModeStep) {
+    if (mode == kModeStep || mode == kModeFpStep) {
       if (timed_now()) {
         ++stats_.cfr_launches;
         stats_.cfr_bytes += part_bytes_[part][trav];
@@ -463,6 +465,22 @@ void Engine::step(int traverser) {
   if (pending_trav_ != traverser) {  // queries on the device were encoded for the other traverser: re-encode
     launch(kModeQueries, 0, traverser, 0, 0, 1, 1, 1);
     pending_trav_ = traverser;
+  }
+  if (!p_.use_cfr) {  // fictitious play (FP::step, subgame_solving.cc:433-476)
+    const int nu = num_strategies_ / 2 + 1;
+    const double alpha_fp = p_.linear_update ? 2. / (nu + 1) : 1. / nu;
+    const double factor = p_.linear_update ? static_cast<double>(nu + 1) / (nu + 2) : 1.0;
+    for (int part = 0; part < n_parts_; ++part) {
+      only_part_ = part;
+      run_net();
+      launch(kModeFpStep, traverser, 1 - traverser, iter_ + 1, alpha_fp, 1, 1, factor);
+    }
+    only_part_ = -1;
+    ++num_strategies_;
+    ++num_steps_[traverser];
+    ++iter_;
+    pending_trav_ = 1 - traverser;
+    return;
   }
   const int k = num_steps_[traverser];
   // running mean step (subgame_solving.cc:580-590) and discounts (:592-617); "+1": the uniform strategy counts
@@ -538,6 +556,7 @@ void Engine::get(int lane, int which, double* out) {
       expand_dense(lane, edge, out);
       return;
     case RBL_GET_REGRETS:
+      if (!p_.use_cfr) throw std::runtime_error("get: regrets exist for CFR only");
       read_lane(d_regrets_.p, lane, &edge);
       expand_dense(lane, edge, out);
       return;
@@ -546,6 +565,11 @@ void Engine::get(int lane, int which, double* out) {
       expand_dense(lane, edge, out);
       return;
     case RBL_GET_AVERAGE: {
+      if (!p_.use_cfr) {  // FP keeps the average strategy itself on the device (it is what reach / sampling use)
+        read_lane(d_sigma_.p, lane, &edge);
+        expand_dense(lane, edge, out);
+        return;
+      }
       // average_strategies = normalised sum_strategies on every node whose mover has stepped (subgame_solving.cc:658-660);
       // rows never touched keep the uniform initialisation (:518-519)
       read_lane(d_sums_.p, lane, &edge);

@@ -13,7 +13,7 @@ from tests.cases import SOLVER_CASES, case_beliefs
 
 pytestmark = pytest.mark.gpu
 
-CFR_CASES = sorted(n for n, c in SOLVER_CASES.items() if c["p"].get("use_cfr"))
+CFR_CASES = sorted(SOLVER_CASES)  # CFR variants and fictitious play
 
 
 def _engine(c, max_lanes=1):
@@ -47,8 +47,9 @@ def test_solver_bit_exact_vs_oracle_and_golden(name, port):
     e.reset([c.get("lb", -1)], [c.get("pl", 0)], b[None])
     assert e.tree_size(0) == o.N
     n_it = c["p"]["num_iters"]
-    pairs = [(capi.GET_AVERAGE, orc.GET_AVERAGE), (capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM),
-             (capi.GET_REGRETS, orc.GET_REGRETS)]
+    pairs = [(capi.GET_AVERAGE, orc.GET_AVERAGE), (capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM)]
+    if c["p"].get("use_cfr"):
+        pairs.append((capi.GET_REGRETS, orc.GET_REGRETS))
     for w, ow in pairs:  # freshly built solver
         assert np.array_equal(e.get(0, w), o.get(ow)), (name, "init", w)
     checkpoints = {1, 2, 3, n_it // 2, n_it}
@@ -61,8 +62,9 @@ def test_solver_bit_exact_vs_oracle_and_golden(name, port):
             if it >= 1:
                 for pl in (0, 1):
                     assert np.array_equal(e.hand_values(0, pl), o.hand_values(pl)), (name, it, pl)
-    arrays = {"average": e.get(0, capi.GET_AVERAGE), "last": e.get(0, capi.GET_LAST), "sum": e.get(0, capi.GET_SUM),
-              "regrets": e.get(0, capi.GET_REGRETS)}
+    arrays = {"average": e.get(0, capi.GET_AVERAGE), "last": e.get(0, capi.GET_LAST), "sum": e.get(0, capi.GET_SUM)}
+    if c["p"].get("use_cfr"):
+        arrays["regrets"] = e.get(0, capi.GET_REGRETS)
     G.check_solver_arrays(name, arrays, np.stack([e.hand_values(0, 0), e.hand_values(0, 1)]), exact=True)
     if c["net"] != "none":
         q, v = e.examples(0)
@@ -199,11 +201,46 @@ def test_queries_bit_exact_first_iteration(port):
     assert np.array_equal(e.queries(), seen[0])
 
 
+@pytest.mark.parametrize("linear,optimistic", [(False, False), (True, False), (False, True), (True, True)])
+def test_fictitious_play_variants_bit_exact(linear, optimistic, port):
+    """FP solver (subgame_solving.cc:364-506) incl. linear and optimistic averaging, heterogeneous lanes, snapshots."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    d, f, iters = 1, 5, 41
+    kw = dict(num_iters=iters, max_depth=2, linear_update=linear, optimistic=optimistic, use_cfr=False)
+    rng = np.random.default_rng(11)
+    roots = [-1, 0, 3, 7, 8, 9, -1]
+    B = len(roots)
+    players = rng.integers(0, 2, B)
+    H = port.num_hands(d, f)
+    beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
+    acts = rng.integers(0, iters + 1, B)
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=B)
+    e.set_net_synthetic()
+    e.reset(roots, players, beliefs, acts)
+    e.multistep()
+    for b in range(B):
+        o = port.solver(d, f, orc.make_params(**kw), roots[b], int(players[b]), beliefs[b], orc.NET_SYNTHETIC)
+        snap = None
+        for it in range(iters):
+            if it == acts[b]:
+                snap = o.get(orc.GET_LAST)
+            o.step(it % 2)
+        if acts[b] == iters:
+            snap = o.get(orc.GET_LAST)
+        for w, ow in [(capi.GET_AVERAGE, orc.GET_AVERAGE), (capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM)]:
+            assert np.array_equal(e.get(b, w), o.get(ow)), (b, roots[b], w)
+        assert np.array_equal(e.get_snapshot(b), snap), (b, acts[b])
+        for pl in (0, 1):
+            assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
+
+
 def test_error_paths():
     from rebel_amd import capi
 
-    with pytest.raises(capi.RebelError):  # FP solver is not on the GPU path
-        capi.Engine(1, 4, capi.make_params(num_iters=4, use_cfr=False))
+    with pytest.raises(capi.RebelError):  # DCFR discounts belong to CFR
+        capi.Engine(1, 4, capi.make_params(num_iters=4, use_cfr=False, dcfr=True))
     e = capi.Engine(1, 4, capi.make_params(num_iters=4, use_cfr=True), max_lanes=2)
     with pytest.raises(capi.RebelError):  # terminal root state
         e.reset([e.A - 1], [0], np.full((1, 2, e.H), 0.25))

@@ -77,3 +77,20 @@ def test_selfplay_2d6f_global_scratch_path(port):
         assert len(ex) == len(ref), seed
         for (q, v), (rq, rv) in zip(ex, ref):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
+
+
+def test_selfplay_fictitious_play_lanes(port):
+    """use_cfr=false is the pybind default (subgame_solving.h:48): self-play with the FP solver (optimistic, linear)
+    reproduces the oracle per seed as well."""
+    from oracle import orc
+
+    c = dict(d=1, f=5, p=dict(num_iters=48, max_depth=2, linear_update=True, optimistic=True, use_cfr=False), rap=0.25,
+             leaf=True, net="synthetic")
+    seeds = [21, 22, 23, 24]
+    lanes = _run_lanes(c, seeds, 3)
+    for seed, ex in zip(seeds, lanes):
+        ref = port.rl_run(c["d"], c["f"], orc.make_params(**c["p"]), seed, 3, random_action_prob=c["rap"],
+                          sample_leaf=c["leaf"], net=orc.NET_SYNTHETIC)
+        assert len(ex) == len(ref), seed
+        for (q, v), (rq, rv) in zip(ex, ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
