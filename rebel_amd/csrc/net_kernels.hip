@@ -888,7 +888,11 @@ __global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const
   // LayerNorm + GELU, row-parallel: thread (row = tid>>3, fg = tid&7) owns features {32 i + 4 fg + r}; the result is
   // written back over the same bytes as f16x2 B fragments in natural k order (k-step i, lane group fg>>1, half fg&1)
   auto epilogue_rows = [&](const float* __restrict__ ln_w, const float* __restrict__ ln_b) {
-    const int row = tid >> 3, fg = tid & 7;
+    // lane bits: [0] = fg bit 0, [1..3] = row bits 0..2, [4..5] = fg bits 1..2; wave = row bits 3..: the 16 lanes that one
+    // ds_write_b64 services together are 8 rows x 2 halves of ONE 256-byte lane group -> 32 distinct banks (with
+    // row = tid >> 3 they were 2 rows x 8 feature groups landing 4-way on the same banks; PMC: 42 % conflict cycles)
+    const int fg = (lane & 1) | ((lane >> 4) << 1);
+    const int row = wave * 8 + ((lane >> 1) & 7);
     f32x4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(&Y[row * kFsYStride + 32 * i + 4 * fg]);
@@ -900,8 +904,8 @@ __global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const
       for (int i = 0; i < 8; ++i) s2 += f32x2{v[i][0], v[i][1]} + f32x2{v[i][2], v[i][3]};
       float s = s2[0] + s2[1];
       s += __shfl_xor(s, 1);
-      s += __shfl_xor(s, 2);
-      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
       const float mean = s * (1.0f / 256.0f);
       f32x2 q2 = splat2(0.f);
 #pragma unroll
@@ -912,8 +916,8 @@ __global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const
       }
       float vs = q2[0] + q2[1];
       vs += __shfl_xor(vs, 1);
-      vs += __shfl_xor(vs, 2);
-      vs += __shfl_xor(vs, 4);
+      vs += __shfl_xor(vs, 16);
+      vs += __shfl_xor(vs, 32);
       const float rstd = 1.0f / sqrtf(vs * (1.0f / 256.0f) + m.ln_eps);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
