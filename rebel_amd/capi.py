@@ -67,6 +67,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever is loaded first serves the whole
+    # process; if librebel_hip.so pulls in /opt/rocm's copy and torch is imported afterwards, torch finds "No HIP GPUs".
+    # Importing torch first (when it is installed) makes the order deterministic; C callers are unaffected.
+    import sys
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing -- build it with `make -C rebel_amd/csrc lib` "
                            "(or __graft_entry__.build()); rebel_amd has no CPU fallback")

@@ -89,7 +89,7 @@ class Engine {
   void get_net_debug(long long* out);  // RBL_NET_DBG=1: phase stamps of the last net forward (first 1024 workgroups)  // RBL_CFR_DBG=1: per-lane phase timestamps of the last CFR launch
 
   // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
-  void read_snapshots(std::vector<double>* snap, std::vector<double>* root_mean);
+  void read_snapshots(const double** snap, const double** root_mean);  // pinned host copies, valid until the next call
 
   void timing(int stride);  // 0 = off, n = time the launches of every n-th CFR iteration with HIP events
   void stats(rbl_kernel_stats* out, bool reset);
@@ -133,6 +133,7 @@ class Engine {
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
   DevBuf<long long> d_dbg_, d_ndbg_;
   DevBuf<double> d_br_;
+  double* h_pinned_ = nullptr;
   DevBuf<float> d_queries_, d_values_, d_mlp_blob_, d_tmp_q_, d_tmp_o_;
 
   std::vector<int> h_shape_, h_player_, h_row_, h_act_, h_bid_;
@@ -190,7 +191,6 @@ class SelfPlay {
   std::vector<std::mt19937> gen_;
   std::vector<int32_t> bid_, player_, act_;
   std::vector<double> beliefs_;  // [n][2][H]
-  std::vector<double> snap_, rmean_;
   std::vector<float> ex_q_, ex_v_;
   std::vector<int32_t> ex_lane_;
   int64_t games_ = 0;
