@@ -44,7 +44,7 @@ def cpu_baseline(dice, faces, iters, seconds):
         out = json.loads(line)
         if "error" in out:
             raise RuntimeError(out["error"])
-        return {k: out[k] for k in ("value", "unit", "cores", "kind", "sample", "threads")}
+        return {k: out[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
     except Exception as ex:  # the reference build is absent: fall back to timing the port oracle (zero net), 1 thread
         from oracle import orc
 
@@ -55,7 +55,7 @@ def cpu_baseline(dice, faces, iters, seconds):
             subgames += len(port.rl_run(dice, faces, p, games, 1, net=orc.NET_SYNTHETIC)) / 2
             games += 1
         return {"value": subgames * iters / (time.time() - t0), "unit": "subgame-CFR-iterations/s", "cores": 1,
-                "kind": "port",
+                "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"reference build unavailable ({ex}); port oracle, 1 thread, {games} games, elementwise "
                           f"synthetic net instead of Net2 (so this OVERSTATES the CPU path)"}
 

@@ -95,8 +95,8 @@ def main():
     time.sleep(a.seconds)
     n1, t1 = replay.num_add(), time.time()
     subgames = (n1 - n0) / 2
-    out = {"value": subgames * a.iters / (t1 - t0), "unit": "subgame-CFR-iterations/s", "cores": os.cpu_count(),
-           "threads": T, "kind": "reference", "subgames_per_s": subgames / (t1 - t0),
+    out = {"value": subgames * a.iters / (t1 - t0), "unit": "subgame-CFR-iterations/s", "cores": T,
+           "host_cores": os.cpu_count(), "threads": T, "kind": "reference", "subgames_per_s": subgames / (t1 - t0),
            "sample": f"{a.dice}dx{a.faces}f, {a.iters} iters/subgame, {T} reference gen threads x {a.seconds:.0f}s window, "
                      f"Net2(256x2,LN) TorchScript on CPU, torch intra-op threads=1"}
     print(json.dumps(out), flush=True)
