@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--faces", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("BENCH_CPU_SECONDS", 20)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -84,8 +85,11 @@ def main():
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: rebel_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rebel_amd import capi
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
@@ -100,7 +104,7 @@ def main():
     sp = capi.SelfPlay(eng, seeds, random_action_prob=0.25, sample_leaf=True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +128,8 @@ def main():
     eng.timing(0)
     games = sp.games_finished() - games0
 
-    dt_max, units_all, games_all = reduce_job(dist, world, dt, float(units), float(games))
+    dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
+                                              float(games)) if use_dist else (dt, float(units), float(games))
 
     if rank == 0:
         net_t = st["net_ms"] / max(1, st["net_launches"]) * 1e-3
@@ -170,7 +175,7 @@ def main():
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
