@@ -775,6 +775,7 @@ __global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const
   const int j = lane & 15, g = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * kFsRows;
   constexpr float kLo = 1.0f / 2048.0f;
+  if (m.stagger >= 2) stagger_sleep(blockIdx.x >= 256 && blockIdx.x < 512, m.stagger);
   long long* dbg = m.dbg && blockIdx.x < 1024 ? m.dbg + (size_t)blockIdx.x * 16 : nullptr;
   int dbg_k = 0;
 #define RBL_NSTAMP()                                              \
