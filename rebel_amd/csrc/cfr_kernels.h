@@ -27,6 +27,8 @@ struct CfrArgs {
   const int* depth;
   const int* leaves;
   const int* terms;
+  const int* irank;     // node -> index of its reach row (root / nodes with children), -1 otherwise (cfr_rows_kernel)
+  const int* leaf_row;  // node -> net row within the lane for pseudo-leaves, -1 otherwise (cfr_rows_kernel)
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
   int H, A, Q, faces, dice;
   int Emax, Nmax;         // per-lane strides: Emax*H reals per strategy array
@@ -72,5 +74,11 @@ inline size_t cfr_work_reals(int N, int H, int L, int T, int dice, int faces) {
 void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream);
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
+
+// cfr_rows_kernel.hip: kModeStep with one thread per tree row, for LDS-resident lanes of the common games.
+// Returns false (nothing launched) when the game has no instantiation.
+size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces);
+bool cfr_rows_supported(int H, int A, int dice, int faces);
+bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
 
 }  // namespace rbl

@@ -1,0 +1,376 @@
+// rebel_amd/csrc/cfr_rows_kernel.hip -- CFR::step for the common games, one thread per tree ROW.
+//
+// cfr_kernels.hip maps one thread to a (node, hand) pair; rocprofv3 PMC showed that kernel issue-bound (SIMDs issuing
+// 84 % of the time, ~2 100 instructions per wave, a third of them scalar control flow) for ~5 kFLOP of real work per
+// lane: almost all of it is index arithmetic and loop control around single fp64 operations.  Here a thread owns a
+// whole row of H hands of one node / edge (H, A, dice, faces are template parameters, so the per-hand loops unroll
+// into straight-line fp64 code on registers, rows move as 16-byte LDS transfers), which amortises every table
+// look-up and address computation over H elements, and folds whole phases together:
+//   * a leaf's reach is never stored: the thread that computes it uses it on the spot for the leaf value (scale sum /
+//     terminal match histogram, both in-thread), and recomputes it for the query row at the end;
+//   * reach rows are kept for nodes with children only (irank table), which shrinks the lane's LDS footprint;
+//   * regret update, regret matching and normalisation of a level run as row-parallel passes over the level's edges
+//     with the sequential-in-action reductions (node value x, row sum s) as row passes over the level's nodes.
+// Arithmetic is operation-for-operation what cfr_kernels.hip does (same operands, same order, -ffp-contract=off), so
+// the bit-exactness contract with the reference (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py
+// runs against this kernel.  Only kModeStep of LDS-resident lanes runs here; init / query-only / best-response / FP
+// modes and big trees stay on the generic kernel (they share the global state layout).
+#include "cfr_kernels.h"
+
+namespace rbl {
+
+namespace {
+
+constexpr double kEps = 1e-80;
+
+template <int H>
+struct Row {
+  double v[H];
+};
+
+template <int H>
+__device__ __forceinline__ Row<H> load_row(const double* p) {
+  Row<H> r;
+#pragma unroll
+  for (int h = 0; h < H; ++h) r.v[h] = p[h];
+  return r;
+}
+template <int H>
+__device__ __forceinline__ void store_row(double* p, const Row<H>& r) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) p[h] = r.v[h];
+}
+
+template <int H, int A, int DICE, int FACES>
+__global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
+  const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
+  const int N = sh.N, E = N - 1, L = sh.L, NI = sh.NI, nlev = sh.nlev;
+  const int root_player = a.lane_root_player[lane], row_off = a.lane_row_off[lane];
+  const int t = a.trav, opp = 1 - t;
+
+  // ---- LDS layout (doubles): rho0, rho1 [NI][H] | sig [E][H] | val [N][H] | reg [E][H] | leaf values | tables
+  double* rho0 = lds;
+  double* rho1 = rho0 + NI * H;
+  double* sig = rho1 + NI * H;
+  double* val = sig + E * H;
+  double* reg = val + N * H;
+  float* lvals = reinterpret_cast<float*>(reg + E * H);
+  int* tb = reinterpret_cast<int*>(lvals + ((L * H + 3) & ~3));
+  int* t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
+  int* t_irank = tb + 5 * N, *t_lrow = tb + 6 * N;
+  int8_t* t_match = reinterpret_cast<int8_t*>(tb + 7 * N);
+  float* qstage = reinterpret_cast<float*>(val);  // [L][Q], aliases val + reg once both are dead (host checks the size)
+
+  const size_t lane_e = (size_t)lane * a.Emax * H;
+  double* g_sig = a.sigma + lane_e;
+  double* g_reg = a.regrets + lane_e;
+  double* g_sum = a.sums + lane_e;
+  const double* bel = a.beliefs + (size_t)lane * 2 * H;
+  double* rmean = a.root_mean + (size_t)lane * 2 * H;
+
+  // ---------------------------------------------------------------- stage (flat, coalesced)
+  {
+    const int* gp = a.parent + sh.node_off;
+    const int* ga = a.act + sh.node_off;
+    const int* gb = a.cb + sh.node_off;
+    const int* ge = a.ce + sh.node_off;
+    const int* gd = a.depth + sh.node_off;
+    const int* gi = a.irank + sh.node_off;
+    const int* gl = a.leaf_row + sh.node_off;
+    const float* gv = a.values + (size_t)row_off * H;
+    const int EH = E * H, LH = L * H;
+    const int n_all = max(max(EH, N), max(LH, FACES * H));
+    for (int i = tid; i < n_all; i += nthr) {
+      if (i < EH) {
+        sig[i] = g_sig[i];
+        reg[i] = g_reg[i];
+      }
+      if (i < LH) lvals[i] = gv[i];
+      if (i < N) {
+        t_parent[i] = gp[i];
+        t_act[i] = ga[i];
+        t_cb[i] = gb[i];
+        t_ce[i] = ge[i];
+        t_depth[i] = gd[i];
+        t_irank[i] = gi[i];
+        t_lrow[i] = gl[i];
+      }
+      if (i < FACES * H) t_match[i] = a.matches[i];
+    }
+    if (tid < H) {
+      rho0[tid] = bel[tid];
+      rho1[tid] = bel[H + tid];
+    }
+    __syncthreads();
+  }
+
+  // value of a node without children, from its opponent-reach row (query_value_net :257-268 / terminal payoffs :80-98)
+  auto leaf_value = [&](int n, const Row<H>& ro) {
+    Row<H> out;
+    if (t_act[n] == A - 1) {  // terminal: the bid that was called is the parent's last bid
+      const int bid = t_act[t_parent[n]];
+      const int qty = 1 + bid / FACES, face = bid % FACES;
+      const int8_t* m = t_match + face * H;
+      double b[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) b[k] = 0.0;
+      double s = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {  // b[m[h]] += r, without dynamic register indexing (x + 0.0 == x for x >= +0)
+        const int mh = m[h];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;
+        s += ro.v[h];
+      }
+#pragma unroll
+      for (int k = NB - 2; k >= 0; --k) b[k] += b[k + 1];
+      const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int left = max(0, qty - (int)m[h]);
+        double bl = b[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) bl = (left == k) ? b[k] : bl;
+        double x = (double)(float)bl * 2 - s;  // fp32 truncation (:785)
+        if (inverse) x *= -1.0;
+        out.v[h] = x;
+      }
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) s += ro.v[h];
+      const float* lv = lvals + t_lrow[n] * H;
+#pragma unroll
+      for (int h = 0; h < H; ++h) out.v[h] = (double)(float)((double)lv[h] * s);
+    }
+    store_row<H>(val + n * H, out);
+  };
+
+  // ---------------------------------------------------------------- reach of both players under sigma, level by level;
+  // rows are stored for nodes with children, leaves turn theirs into a value right away
+  if (tid == 0 && t_cb[0] == t_ce[0]) leaf_value(0, load_row<H>(opp == 0 ? rho0 : rho1));
+  for (int lev = 1; lev < nlev; ++lev) {
+    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
+    const int mover = root_player ^ ((lev - 1) & 1);
+    for (int n = n0 + tid; n < n1; n += nthr) {
+      const int pr = t_irank[t_parent[n]];
+      Row<H> r0 = load_row<H>(rho0 + pr * H), r1 = load_row<H>(rho1 + pr * H);
+      const Row<H> s = load_row<H>(sig + (n - 1) * H);
+      if (mover == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) r0.v[h] = r0.v[h] * s.v[h];
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) r1.v[h] = r1.v[h] * s.v[h];
+      }
+      const int ir = t_irank[n];
+      if (ir >= 0) {
+        store_row<H>(rho0 + ir * H, r0);
+        store_row<H>(rho1 + ir * H, r1);
+      } else {
+        leaf_value(n, opp == 0 ? r0 : r1);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- bottom-up (update_regrets :542-574) fused with regret
+  // matching (:619-634) and the regret discount (:639-650)
+  double* rho_t = t == 0 ? rho0 : rho1;
+  for (int lev = nlev - 2; lev >= 0; --lev) {
+    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
+    const int c_lo = sh.lev_off[lev + 1], c_hi = sh.lev_off[lev + 2];
+    const bool mine = (root_player ^ (lev & 1)) == t;
+    for (int n = n0 + tid; n < n1; n += nthr) {  // node value: sequential over the actions
+      const int c0 = t_cb[n], c1 = t_ce[n];
+      if (c0 == c1) continue;
+      Row<H> x;
+#pragma unroll
+      for (int h = 0; h < H; ++h) x.v[h] = 0.0;
+      for (int c = c0; c < c1; ++c) {
+        const Row<H> vc = load_row<H>(val + c * H);
+        if (mine) {
+          const Row<H> sc = load_row<H>(sig + (c - 1) * H);
+#pragma unroll
+          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h] * sc.v[h];
+        } else {
+#pragma unroll
+          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h];
+        }
+      }
+      store_row<H>(val + n * H, x);
+    }
+    __syncthreads();
+    if (!mine) continue;
+    for (int c = c_lo + tid; c < c_hi; c += nthr) {  // one thread per edge into the level below
+      const int p = t_parent[c];
+      const Row<H> vc = load_row<H>(val + c * H), xp = load_row<H>(val + p * H);
+      Row<H> r = load_row<H>(reg + (c - 1) * H), m;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        double q = r.v[h];
+        q += vc.v[h];
+        q -= xp.v[h];
+        m.v[h] = q > kEps ? q : kEps;
+        r.v[h] = q * (q > 0 ? a.pos : a.neg);
+      }
+      store_row<H>(sig + (c - 1) * H, m);
+      store_row<H>(reg + (c - 1) * H, r);
+    }
+    __syncthreads();
+    for (int n = n0 + tid; n < n1; n += nthr) {  // row sums, sequential over the actions; parked in the (dead) rho_t row
+      const int c0 = t_cb[n], c1 = t_ce[n];
+      if (c0 == c1) continue;
+      Row<H> s;
+#pragma unroll
+      for (int h = 0; h < H; ++h) s.v[h] = 0.0;
+      for (int c = c0; c < c1; ++c) {
+        const Row<H> mc = load_row<H>(sig + (c - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) s.v[h] += mc.v[h];
+      }
+      store_row<H>(rho_t + t_irank[n] * H, s);
+    }
+    __syncthreads();
+    for (int c = c_lo + tid; c < c_hi; c += nthr) {
+      const Row<H> s = load_row<H>(rho_t + t_irank[t_parent[c]] * H);
+      Row<H> m = load_row<H>(sig + (c - 1) * H);
+#pragma unroll
+      for (int h = 0; h < H; ++h) m.v[h] = m.v[h] / s.v[h];
+      store_row<H>(sig + (c - 1) * H, m);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- running mean of the root values (:579-590)
+  if (tid < H) {
+    double m = rmean[t * H + tid];
+    m += (val[tid] - m) * a.alpha;
+    rmean[t * H + tid] = m;
+    rho_t[tid] = bel[t * H + tid];  // root row of the traverser (it served as scratch above)
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638), rows
+  // of nodes with children only
+  for (int lev = 1; lev < nlev - 1; ++lev) {
+    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
+    const bool own = (root_player ^ ((lev - 1) & 1)) == t;
+    for (int n = n0 + tid; n < n1; n += nthr) {
+      const int ir = t_irank[n];
+      if (ir < 0) continue;
+      Row<H> r = load_row<H>(rho_t + t_irank[t_parent[n]] * H);
+      if (own) {
+        const Row<H> s = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) r.v[h] = r.v[h] * s.v[h];
+      }
+      store_row<H>(rho_t + ir * H, r);
+    }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
+  {
+    const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after;
+    double* snap = a.snapshot + lane_e;
+    for (int c = 1 + tid; c < N; c += nthr) {
+      const int p = t_parent[c], e = (c - 1) * H;
+      const Row<H> s = load_row<H>(sig + e);
+      if ((root_player ^ (t_depth[p] & 1)) == t) {
+        const Row<H> rp = load_row<H>(rho_t + t_irank[p] * H);
+        const Row<H> rg = load_row<H>(reg + e);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          double x = g_sum[e + h];
+          x *= a.strat;
+          x += rp.v[h] * s.v[h];
+          g_sum[e + h] = x;
+          g_sig[e + h] = s.v[h];
+          g_reg[e + h] = rg.v[h];
+        }
+      }
+      if (snap_now) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) snap[e + h] = s.v[h];
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
+  if (a.next_trav >= 0 && L > 0) {
+    __syncthreads();  // val / reg are dead from here on: their bytes stage the query rows
+    const int* gleaves = a.leaves + sh.leaf_off;
+    for (int k = tid; k < L; k += nthr) {
+      const int n = gleaves[k];
+      float* q = qstage + k * Q;
+      Row<H> r0, r1;
+      const int ir = t_irank[n];
+      if (ir >= 0) {  // only the root can be a pseudo-leaf with a stored row (max_depth = 0)
+        r0 = load_row<H>(rho0 + ir * H);
+        r1 = load_row<H>(rho1 + ir * H);
+      } else {
+        const int p = t_parent[n], pr = t_irank[p];
+        r0 = load_row<H>(rho0 + pr * H);
+        r1 = load_row<H>(rho1 + pr * H);
+        const Row<H> s = load_row<H>(sig + (n - 1) * H);
+        if ((root_player ^ (t_depth[p] & 1)) == 0) {
+#pragma unroll
+          for (int h = 0; h < H; ++h) r0.v[h] = r0.v[h] * s.v[h];
+        } else {
+#pragma unroll
+          for (int h = 0; h < H; ++h) r1.v[h] = r1.v[h] * s.v[h];
+        }
+      }
+      double s0 = 0, s1 = 0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) s0 += r0.v[h] + kEps;  // normalize_probabilities_safe (util.h:68-78)
+#pragma unroll
+      for (int h = 0; h < H; ++h) s1 += r1.v[h] + kEps;
+      q[0] = (float)(root_player ^ (t_depth[n] & 1));
+      q[1] = (float)a.next_trav;
+      const int lb = t_act[n];
+#pragma unroll
+      for (int j = 0; j < A; ++j) q[2 + j] = (j == lb) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[2 + A + h] = (float)((r0.v[h] + kEps) / s0);
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[2 + A + H + h] = (float)((r1.v[h] + kEps) / s1);
+    }
+    __syncthreads();
+    float* gq = a.queries + (size_t)row_off * Q;
+    for (int i = tid; i < L * Q; i += nthr) gq[i] = qstage[i];
+  }
+}
+
+}  // namespace
+
+size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces) {
+  size_t d = (size_t)2 * NI * H + (size_t)(N - 1) * H + (size_t)N * H + (size_t)(N - 1) * H;  // doubles
+  size_t b = d * 8 + (size_t)((L * H + 3) & ~3) * 4 + (size_t)7 * N * 4 + (size_t)faces * H;
+  return (b + 15) & ~(size_t)15;
+}
+
+bool cfr_rows_supported(int H, int A, int dice, int faces) {
+  return (H == 6 && A == 13 && dice == 1 && faces == 6) || (H == 4 && A == 9 && dice == 1 && faces == 4) ||
+         (H == 5 && A == 11 && dice == 1 && faces == 5) || (H == 9 && A == 13 && dice == 2 && faces == 3);
+}
+
+bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream) {
+#define RBL_ROWS(H_, A_, D_, F_)                                                                              \
+  do {                                                                                                        \
+    hipLaunchKernelGGL((cfr_rows_kernel<H_, A_, D_, F_>), dim3(B), dim3(block), lds_bytes, stream, a);        \
+    return true;                                                                                              \
+  } while (0)
+  if (a.H == 6 && a.A == 13 && a.dice == 1) RBL_ROWS(6, 13, 1, 6);
+  if (a.H == 4 && a.A == 9 && a.dice == 1) RBL_ROWS(4, 9, 1, 4);
+  if (a.H == 5 && a.A == 11 && a.dice == 1) RBL_ROWS(5, 11, 1, 5);
+  if (a.H == 9 && a.A == 13 && a.dice == 2) RBL_ROWS(9, 13, 2, 3);
+#undef RBL_ROWS
+  return false;
+}
+
+}  // namespace rbl

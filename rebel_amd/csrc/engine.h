@@ -127,7 +127,7 @@ class Engine {
   hipStream_t part_stream(int part) const { return part == 0 ? stream_ : part == 1 ? stream2_ : stream_x_[part - 2]; }
 
   DevBuf<ShapeDev> d_shapes_;
-  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_;
+  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_;
   DevBuf<int8_t> d_matches_;
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
@@ -153,6 +153,9 @@ class Engine {
   std::vector<float> h_q_, h_v_;
 
   int block_ = 64;
+  bool rows_ok_ = false;  // kModeStep runs on cfr_rows_kernel (one thread per tree row)
+  int rows_block_ = 128;
+  size_t rows_lds_bytes_ = 0;
   size_t lds_bytes_ = 0, work_stride_ = 0;
   bool use_lds_ = true;
 

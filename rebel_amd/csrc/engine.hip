@@ -73,6 +73,8 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   d_depth_.upload(tabs_.depth, stream_);
   d_leaves_.upload(tabs_.leaves, stream_);
   d_terms_.upload(tabs_.terms, stream_);
+  d_irank_.upload(tabs_.irank, stream_);
+  d_leaf_row_.upload(tabs_.leaf_row, stream_);
   std::vector<int8_t> m((size_t)g_.faces * g_.H);
   for (int f = 0; f < g_.faces; ++f)
     for (int h = 0; h < g_.H; ++h) m[(size_t)f * g_.H + h] = (int8_t)g_.matches(h, f);
@@ -105,6 +107,17 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   const int nh = nmax_ * g_.H;
   block_ = nh <= 128 ? 64 : (nh <= 384 ? 128 : 256);  // measured on MI355X: 1dx6f (546 pairs) 256 > 128 > 64
   block_ = env_int("RBL_CFR_BLOCK", block_);
+  // CFR::step proper runs on the row-per-thread kernel when the game has an instantiation and every shape of this
+  // engine fits its LDS layout (including the query rows staged over the dead val/reg/leaf-value bytes)
+  rows_ok_ = use_lds_ && env_int("RBL_CFR_ROWS", 1) && cfr_rows_supported(g_.H, g_.A, g_.dice, g_.faces);
+  rows_lds_bytes_ = 0;
+  for (const ShapeDev& s : tabs_.shapes) {
+    rows_lds_bytes_ = std::max(rows_lds_bytes_, cfr_rows_lds_bytes(s.N, s.NI, g_.H, s.L, g_.faces));
+    const size_t stage = (size_t)(2 * s.N - 1) * g_.H * 8;
+    if ((size_t)s.L * g_.query_size() * 4 > stage) rows_ok_ = false;
+  }
+  if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
+  rows_block_ = env_int("RBL_CFR_ROWS_BLOCK", 128);
   if (env_int("RBL_CFR_DBG", 0)) {
     d_dbg_.alloc(L * 16);
     RBL_HIP_CHECK(hipMemset(d_dbg_.p, 0, L * 16 * sizeof(long long)));
@@ -373,6 +386,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.depth = d_depth_.p;
   a.leaves = d_leaves_.p;
   a.terms = d_terms_.p;
+  a.irank = d_irank_.p;
+  a.leaf_row = d_leaf_row_.p;
   a.matches = d_matches_.p;
   a.H = g_.H;
   a.A = g_.A;
@@ -414,7 +429,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     hipStream_t st = part_stream(part);
     a.lane0 = l0;
     time_begin(0, st);
-    launch_cfr(a, cnt, block_, lds_bytes_, st);
+    if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, rows_block_, rows_lds_bytes_, st)))
+      launch_cfr(a, cnt, block_, lds_bytes_, st);
     time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
     if (mode == kModeStep || mode == kModeFpStep) {

@@ -70,6 +70,7 @@ inline std::vector<Node> unroll_tree(const Rules& g, int root_bid, int root_play
 struct ShapeDev {
   int node_off;  // first node of this shape in parent/act/cb/ce/leaf_row
   int N, L, T;   // nodes, pseudo-leaves (net rows), terminals
+  int NI;        // nodes that keep a reach row: the root and every node with children (irank >= 0)
   int leaf_off;  // into `leaves` (node ids, ascending = net row order, subgame_solving.cc:189-195)
   int term_off;  // into `terms`  (node ids, ascending, :198-202)
   int nlev;      // number of BFS levels present
@@ -78,7 +79,7 @@ struct ShapeDev {
 
 struct ShapeTables {
   std::vector<ShapeDev> shapes;  // index = root_last_bid + 1
-  std::vector<int> parent, act, cb, ce, depth, leaf_row, leaves, terms;
+  std::vector<int> parent, act, cb, ce, depth, leaf_row, irank, leaves, terms;
   int max_N = 0, max_L = 0, max_T = 0;
 
   // has_net=false reproduces the reference's refusal to build a truncated tree without a value net
@@ -117,6 +118,7 @@ struct ShapeTables {
         t.ce.push_back(n.ce);
         t.depth.push_back(n.depth);
         t.leaf_row.push_back(row);
+        t.irank.push_back((i == 0 || n.cb != n.ce) ? s.NI++ : -1);
       }
       s.nlev = lev + 1;
       for (int d = s.nlev; d <= kMaxLevels; ++d) s.lev_off[d] = s.N;
