@@ -179,7 +179,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   if (w.n_out != g_.H)
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
-  const int tile = env_int("RBL_MLP_TILE", 3);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
+  const int tile = env_int("RBL_MLP_TILE", 5);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be

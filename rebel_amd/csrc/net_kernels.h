@@ -42,6 +42,10 @@ MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, 
 
 bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
 
+// net_resident_kernel.hip (tile 5): persistent workgroups with register-resident weights; one hidden layer of 256 only
+bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out);
+void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
+
 // out[rows][n_out] = net(queries[rows][n_in]); fp32 MFMA (v_mfma_f32_32x32x2_f32), async on `stream`.
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
 

@@ -1210,9 +1210,13 @@ static MlpPacked pack_mlp_f16x2(int n_layers, int n_in, int n_hidden, int n_out,
 //   output  : [tile][k-step 8][part]
 static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                                  const float* const* b, const float* const* ln_w, const float* const* ln_b,
-                                 const float* w_out, const float* b_out, int waves) {
+                                 const float* w_out, const float* b_out, int waves, bool resident = false) {
+  // resident (tile 5, net_resident_kernel.hip): lo halves are the plain remainders (no 2^11 pre-scale), the layers after
+  // the first carry the sqrt2 that the kernel's GELU leaves out, and ln_b is stored divided by sqrt2
   MlpPacked p;
-  p.tile = waves == 4 ? 4 : 3;
+  p.tile = resident ? 5 : (waves == 4 ? 4 : 3);
+  const float lo_scale = resident ? 1.0f : 2048.0f;
+  const double post = resident ? -1.41421356237309504880 : 1.0, pre = resident ? 0.70710678118654752440 : 1.0;
   const int NW = waves == 4 ? 4 : 8, OTW = 16 / NW;
   const int KS = 8;
   const int ks0 = (n_in + 31) / 32;
@@ -1239,13 +1243,14 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
     if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
     return std::ldexp(1.0f, (int)std::floor(std::log2(8192.0f / mx)));
   };
-  auto put = [&](size_t frag, const float* W, int ld, int n_rows, int n_cols, int i0, int ks, float S, int part) {
+  auto put = [&](size_t frag, const float* W, int ld, int n_rows, int n_cols, int i0, int ks, float S, int part,
+                 double fold = 1.0) {
     for (int lane = 0; lane < 64; ++lane)
       for (int e = 0; e < 8; ++e) {
         const int i = i0 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
-        const float v = (i < n_rows && k < n_cols) ? W[(size_t)i * ld + k] * S : 0.f;
+        const float v = (i < n_rows && k < n_cols) ? (float)((double)W[(size_t)i * ld + k] * S * fold) : 0.f;
         const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        const _Float16 lo = (_Float16)((v - (float)hi) * lo_scale);
         tape[(frag * 64 + lane) * 8 + e] = part == 0 ? hi : lo;
       }
   };
@@ -1269,7 +1274,7 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
         for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
             put(frag_wh + ((((size_t)(l - 1) * NW + wv) * KS + ks) * OTW + ot) * 2 + part, w[l], n_hidden, n_hidden,
-                n_hidden, 16 * (OTW * wv + ot), ks, S, part);
+                n_hidden, 16 * (OTW * wv + ot), ks, S, part, post);
   }
   {
     const float S = scale_of(w_out, (size_t)n_out * n_hidden);
@@ -1277,13 +1282,13 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
     for (int ot = 0; ot < p.out_tiles; ++ot)
       for (int ks = 0; ks < KS; ++ks)
         for (int part = 0; part < 2; ++part)
-          put(frag_wo + ((size_t)ot * KS + ks) * 2 + part, w_out, n_hidden, n_out, n_hidden, 16 * ot, ks, S, part);
+          put(frag_wo + ((size_t)ot * KS + ks) * 2 + part, w_out, n_hidden, n_out, n_hidden, 16 * ot, ks, S, part, post);
   }
   for (int l = 0; l < n_layers; ++l)
     for (int i = 0; i < n_hidden; ++i) {
       p.blob[p.off_bias + (size_t)l * n_hidden + i] = b[l][i];
       p.blob[p.off_lnw + (size_t)l * n_hidden + i] = use_ln ? ln_w[l][i] : 1.f;
-      p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? ln_b[l][i] : 0.f;
+      p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? (float)((double)ln_b[l][i] * pre) : 0.f;
     }
   for (int i = 0; i < n_out; ++i) p.blob[p.off_bout + i] = b_out[i];
   return p;
@@ -1294,6 +1299,9 @@ MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, 
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error("value net shape not supported by the MFMA forward (n_hidden in {64,128,256}, n_out <= 64)");
+  if (tile == 5 && mlp_resident_supported(n_layers, n_in, n_hidden, n_out))
+    return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, 8, true);
+  if (tile == 5) tile = 3;
   if ((tile == 3 || tile == 4) && n_hidden == 256 && n_out <= 64 && n_layers <= 7 && n_in <= 128)
     return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, tile == 4 ? 4 : 8);
   if ((tile == 2 || tile == 3 || tile == 4) && n_hidden == 256 && n_out <= 64 && n_layers <= 7)
@@ -1378,6 +1386,7 @@ static void launch_mlp16(const MlpDev& m, const float* queries, int64_t rows, fl
 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
   if (rows <= 0) return;
+  if (m.tile == 5) return launch_mlp_resident(m, queries, rows, out, stream);
   if (m.tile == 3 || m.tile == 4) {
 #define RBL_FS(OT_, W_) \
   hipLaunchKernelGGL((mlp_fsplit_forward_kernel<OT_, W_>), dim3((unsigned)((rows + W_ * 8 - 1) / (W_ * 8))), dim3(W_ * 64), \

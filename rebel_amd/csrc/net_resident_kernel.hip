@@ -1,0 +1,434 @@
+// rebel_amd/csrc/net_resident_kernel.hip -- value-net forward with REGISTER-RESIDENT weights (MlpDev::tile == 5).
+//
+// Why another variant.  The feature-split kernel (net_kernels.hip, tile 3) re-reads every weight fragment from L2 once
+// per 64-row workgroup: 290 KB per 64 rows, 1.2 GB per 270k-row launch, ~65 % of what the L2 -> CU path can deliver while
+// the GEMM phases run.  A build with the weight loads hoisted out of the k loop ran the hidden-layer GEMM phase in 4.7 K
+// cycles instead of 8.5 K: the phase was bound by weight delivery, not by the matrix pipe.  Two more measurements
+// (scripts/micro/) shaped this kernel:
+//   * on gfx950 the f16 MFMA pipe and the f32 FMA/MUL VALU ops do NOT overlap, not even across waves of one SIMD (times
+//     add to within 5 %), so running GEMM and LayerNorm/GELU phases concurrently in different workgroups buys nothing;
+//     what counts is that each phase runs at its own pipe's rate and that the VALU phase is short;
+//   * v_mfma_f32_16x16x32_f16 honours f16 subnormals, so the low halves of the f16x2 split need no 2^11 pre-scale and
+//     all three partial products can go into ONE f32 accumulator.
+// Hence: a PERSISTENT workgroup per CU (8 waves, 2 per SIMD, 256-VGPR budget).  Wave w owns output features
+// [32w, 32w+32) of both dense layers and keeps its slice of the weights -- layer 0 (16 VGPRs) and the 256x256 hidden layer
+// (128 VGPRs, hi + lo halves) -- in registers for the whole launch, looping over 64-row groups.  Weight traffic drops from
+// once per group to once per workgroup (16x fewer bytes at 270k rows).  The next group's query rows are fetched into
+// registers while the current group computes.  Activations are exchanged through LDS exactly as in the tile-3 kernel
+// (row-major f32 image of the pre-activations, rewritten in place as f16x2 MFMA B fragments).
+//
+// VALU diet (the epilogue is ~55 % of the remaining time): GELU is evaluated on z = x / sqrt2 and returns GELU(x) / sqrt2
+// = max(z, 0) - t erfc(t) / 2 with t = min(|z|, 4) and erfc(t) / 2 = 2^(t R(t) - 1) (R as in net_kernels.hip); the
+// 1 / sqrt2 going in is folded into the LayerNorm scale and shift (host: ln_b / sqrt2), the sqrt2 coming out into the
+// next layer's weights (host: W * sqrt2).  15 VALU instructions per element pair instead of 19; LayerNorm keeps the
+// centred values from the variance pass (5 instead of 6); the split needs no rescale (5 instead of 6); one accumulator
+// means one fma per pair to form the pre-activation (1 instead of 2).
+//
+// Supported shape: n_layers == 2 (one hidden layer, the reference's configuration liars_sp.yaml:28-33), n_hidden == 256,
+// n_in <= 128, n_out <= 64.  Anything else stays on the tile-3 kernel.
+#include <stdexcept>
+
+#include "net_kernels.h"
+
+namespace rbl {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+union Frag {
+  f32x4 v;
+  f16x8 h;
+};
+
+constexpr int kRows = 64, kRT = 4, kKS = 8, kOTW = 2, kWaves = 8;
+constexpr int kYStride = 260;  // f32 per image row (+4: conflict-free 16-byte column writes)
+constexpr int kImageBytes = kRows * kYStride * 4;
+
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+// -GELU(sqrt2 z) / sqrt2 for two elements (see the header; the sign goes into the next layer's weights too)
+__device__ __forceinline__ f32x2 gelu_z(f32x2 z) {
+  const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(z), splat2(4.0f));
+  f32x2 r = splat2(-4.535757872e-05f);
+  r = fma2(r, t, splat2(4.454992795e-04f));
+  r = fma2(r, t, splat2(-1.489414726e-03f));
+  r = fma2(r, t, splat2(-7.746730062e-04f));
+  r = fma2(r, t, splat2(2.825371816e-02f));
+  r = fma2(r, t, splat2(-1.484816315e-01f));
+  r = fma2(r, t, splat2(-9.184163899e-01f));
+  r = fma2(r, t, splat2(-1.627908593e+00f));
+  r = fma2(r, t, splat2(-1.0f));
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
+  return fma2(t, e, __builtin_elementwise_min(-z, splat2(0.0f)));
+}
+
+// two f32 -> (hi, lo) f16 pairs, lo = the exact remainder (subnormal f16 lo parts are fine: the MFMA honours them)
+__device__ __forceinline__ void split2(float a, float b, f16x2* hi, f16x2* lo) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+  // remainder = a - (f32)hi in ONE instruction each (mixed-precision fma; hipcc only selects it with f32 denormals off)
+  float ra, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h), "v"(b));
+  *hi = h;
+  *lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
+// sum over the 8 lanes {l ^ 1, l ^ 16, l ^ 32} that share an image row, on the VALU (DPP + the gfx950 row / half swaps)
+// instead of three ds_bpermute round trips
+__device__ __forceinline__ float row_sum8(float s) {
+  s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));
+  // v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of one register with the even rows (lower
+  // half) of ANOTHER: copy, swap, add.  Written as asm: hipcc 7.2 mis-models the builtin's second result.
+  float c;
+  asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "=&v"(c));
+  s += c;
+  asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "=&v"(c));
+  return s + c;
+}
+
+#define RBL_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_f16((A_), (B_), (C_), 0, 0, 0)
+
+// One dense layer for this wave's 2 x 4 output tiles with the weights already in registers.  A "step" is one (k-step,
+// row tile): two B fragments (hi, lo) from LDS feed 6 MFMAs (small products first, all into the same accumulator).
+// hipcc on its own emits "4 ds_reads, wait, 12 MFMAs" with nothing in flight across the wait; the sched_barriers pin a
+// 3-slot ring instead: the fragments of step s+2 are requested before the MFMAs of step s issue, so every LDS round trip
+// has ~200 cycles of matrix work in front of it.
+template <int NKS>
+__device__ __forceinline__ void gemm_resident(const Frag (&wh)[NKS][kOTW], const Frag (&wl)[NKS][kOTW],
+                                              const f32x4* __restrict__ X, int lane, f32x4 (&acc)[kOTW][kRT]) {
+  constexpr int NS = NKS * kRT, PF = 2;
+  Frag xb[PF + 1][2];
+#pragma unroll
+  for (int s = 0; s < PF && s < NS; ++s) {
+    xb[s][0].v = X[(((s / kRT) * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
+    xb[s][1].v = X[(((s / kRT) * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int ks = s / kRT, rt = s % kRT, slot = s % (PF + 1);
+    if (s + PF < NS) {
+      const int n = s + PF, nslot = n % (PF + 1);
+      xb[nslot][0].v = X[(((n / kRT) * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
+      xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wl[ks][ot].h, xb[slot][0].h, acc[ot][rt]);
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wh[ks][ot].h, xb[slot][1].h, acc[ot][rt]);
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wh[ks][ot].h, xb[slot][0].h, acc[ot][rt]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// K0C: 32-wide k chunks of the input layer (1 for n_in <= 32: its weights stay resident); LN: LayerNorm on / off
+template <int K0C, bool LN>
+__global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
+                                                                    int64_t rows, float* __restrict__ out, int n_groups) {
+  constexpr int kStageFloats = kRows * 32 * K0C;
+  constexpr int NQ = (kStageFloats + kWaves * 64 - 1) / (kWaves * 64);
+  constexpr int kParamFloats = 2 * 3 * 256;  // per layer: bias, gamma, beta / sqrt2
+  constexpr int kWoF4 = kKS * 2 * 64;        // one output tile's weight fragments (16 KB)
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStageFloats * 4 + kRT * 64 * 16 + kParamFloats * 4 + kWoF4 * 16];
+  float* Y = reinterpret_cast<float*>(smem);                                   // [64][260] f32 pre-activations
+  f32x4* X = reinterpret_cast<f32x4*>(smem);                                   // [ks][hi,lo][row tile][lane] B fragments
+  unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
+  float* qs = reinterpret_cast<float*>(smem + kImageBytes);                    // [64][n_in] raw queries of the next group
+  f32x4* P = reinterpret_cast<f32x4*>(smem + kImageBytes + kStageFloats * 4);  // [row tile][lane] output partials
+  float* prm = reinterpret_cast<float*>(P + kRT * 64);                         // [layer][bias, gamma, beta'][256]
+  f32x4* Wo = reinterpret_cast<f32x4*>(prm + kParamFloats);                    // [ks][hi,lo][lane] of output tile 0
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 15, g = lane >> 4;
+  const int n_in = m.n_in, q_elems = kRows * n_in;
+  long long* dbg = m.dbg && blockIdx.x < 1024 ? m.dbg + (size_t)blockIdx.x * 16 : nullptr;
+  int dbg_k = 0;
+#define RBL_NSTAMP()                                              \
+  do {                                                            \
+    if (dbg && tid == 0) dbg[dbg_k] = (long long)clock64();       \
+    ++dbg_k;                                                      \
+  } while (0)
+
+  // ---------------------------------------------------------------- this wave's weights, resident for the whole launch
+  const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
+  Frag w0h[1][kOTW], w0l[1][kOTW];
+  if constexpr (K0C == 1) {
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot) {
+      w0h[0][ot].v = blob[((size_t)wave * kOTW + ot) * 2 * 64 + lane];
+      w0l[0][ot].v = blob[(((size_t)wave * kOTW + ot) * 2 + 1) * 64 + lane];
+    }
+  }
+  Frag w1h[kKS][kOTW], w1l[kKS][kOTW];
+  {
+    const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
+#pragma unroll
+    for (int ks = 0; ks < kKS; ++ks)
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot) {
+        w1h[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+        w1l[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+      }
+  }
+  // per-feature parameters and the first output tile's weights: LDS copies (read every group, by every thread)
+  for (int i = tid; i < 256; i += kWaves * 64) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      prm[(l * 3 + 0) * 256 + i] = m.bias[l * 256 + i];
+      prm[(l * 3 + 1) * 256 + i] = m.ln_w[l * 256 + i];
+      prm[(l * 3 + 2) * 256 + i] = m.ln_b[l * 256 + i];
+    }
+  }
+  for (int i = tid; i < kWoF4; i += kWaves * 64) Wo[i] = reinterpret_cast<const f32x4*>(m.wo)[i];
+
+  f32x4 bout0;  // output bias of tile 0, features 4g .. 4g+3
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bout0[r] = 4 * g + r < m.n_out ? m.b_out[4 * g + r] : 0.f;
+
+  // raw query rows of group `grp` -> registers (coalesced; rows past the end read as zero)
+  float qn[NQ];
+  auto fetch_queries = [&](int grp) {
+    const int64_t base = (int64_t)grp * q_elems, total = rows * n_in;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = i * (kWaves * 64) + tid;
+      qn[i] = (grp < n_groups && e < q_elems && base + e < total) ? queries[base + e] : 0.f;
+    }
+  };
+  auto park_queries = [&]() {
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int e = i * (kWaves * 64) + tid;
+      if (e < q_elems) qs[e] = qn[i];
+    }
+  };
+
+  f32x4 acc[kOTW][kRT];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot)
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) acc[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // pre-activations (+ bias) of this wave's 32 features -> row-major image; everybody must be done READING X first
+  auto write_y = [&](float inv_s, const float* bias) {
+    __syncthreads();
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot) {
+      const int f0 = 16 * kOTW * wave + 16 * ot + 4 * g;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt)
+        *reinterpret_cast<f32x4*>(&Y[(rt * 16 + j) * kYStride + f0]) = acc[ot][rt] * inv_s + b4;
+    }
+    __syncthreads();
+  };
+
+  // LayerNorm + GELU, row-parallel (thread = row, 8 x 4 features {32 i + 4 fg + r}), result written back over the same
+  // bytes as f16x2 B fragments.  Lane -> (row, fg) mapping as in net_kernels.hip (conflict-free 8-byte fragment writes).
+  auto epilogue_rows = [&](const float* pl) {
+    const int fg = (lane & 1) | ((lane >> 4) << 1);
+    const int row = wave * 8 + ((lane >> 1) & 7);
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(&Y[row * kYStride + 32 * i + 4 * fg]);
+    __syncthreads();  // the image is about to be overwritten by the next layer's operands
+    constexpr float kC = 0.70710678118654752440f;
+    float rs = kC;
+    if constexpr (LN) {
+      f32x2 s2 = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s2 += f32x2{v[i][0], v[i][1]} + f32x2{v[i][2], v[i][3]};
+      const float mean = row_sum8(s2[0] + s2[1]) * (1.0f / 256.0f);
+      f32x2 q2 = splat2(0.f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 d0 = f32x2{v[i][0], v[i][1]} - splat2(mean), d1 = f32x2{v[i][2], v[i][3]} - splat2(mean);
+        q2 = fma2(d0, d0, q2);
+        q2 = fma2(d1, d1, q2);
+        v[i] = f32x4{d0[0], d0[1], d1[0], d1[1]};
+      }
+      const float var = row_sum8(q2[0] + q2[1]) * (1.0f / 256.0f) + m.ln_eps;
+      float y0 = __builtin_amdgcn_rsqf(var);  // v_rsq_f32 (1 ulp) + one Newton step
+      y0 = y0 * __builtin_fmaf(-0.5f * var, y0 * y0, 1.5f);
+      rs = kC * y0;
+    }
+    const int rt = row >> 4, lane2 = (fg >> 1) * 16 + (row & 15);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(pl + 256 + 32 * i + 4 * fg);
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(pl + 512 + 32 * i + 4 * fg);  // beta / sqrt2
+      f32x2 y[2];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const f32x2 a = f32x2{g4[2 * h2], g4[2 * h2 + 1]} * splat2(rs);
+        y[h2] = gelu_z(fma2(f32x2{v[i][2 * h2], v[i][2 * h2 + 1]}, a, f32x2{o4[2 * h2], o4[2 * h2 + 1]}));
+      }
+      f16x2 h0, l0, h1, l1;
+      split2(y[0][0], y[0][1], &h0, &l0);
+      split2(y[1][0], y[1][1], &h1, &l1);
+      const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
+      X8[(((i * 2 + 0) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, hh);
+      X8[(((i * 2 + 1) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, ll);
+    }
+    __syncthreads();
+  };
+
+  // ---------------------------------------------------------------- prologue: first group's queries -> LDS
+  fetch_queries(blockIdx.x);
+  park_queries();
+  __syncthreads();
+
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t row0 = (int64_t)grp * kRows;
+    RBL_NSTAMP();  // 0
+    // -------------------------------------------------------------- parked queries -> f16x2 B fragments
+    if (tid < kRT * 64) {
+      const int rt = tid >> 6;
+      const float* qrow = qs + (rt * 16 + j) * n_in;
+#pragma unroll
+      for (int ks = 0; ks < K0C; ++ks) {
+        f16x2 h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = 32 * ks + 8 * g + 2 * e;
+          const float q0 = k < n_in ? qrow[k] : 0.f, q1 = k + 1 < n_in ? qrow[k + 1] : 0.f;
+          split2(q0, q1, &h[e], &l[e]);
+        }
+        Frag fh, fl;
+        fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+        fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+        X[((ks * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
+        X[((ks * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
+      }
+    }
+    __syncthreads();
+    fetch_queries(grp + gridDim.x);  // in flight until the end of this group
+    RBL_NSTAMP();  // 1: staged
+
+    // -------------------------------------------------------------- layer 0
+    zero_acc();
+    if constexpr (K0C == 1) {
+      gemm_resident<1>(w0h, w0l, X, lane, acc);
+    } else {
+      const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64;
+      Frag th[K0C][kOTW], tl[K0C][kOTW];
+#pragma unroll
+      for (int ks = 0; ks < K0C; ++ks)
+#pragma unroll
+        for (int ot = 0; ot < kOTW; ++ot) {
+          th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+          tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        }
+      gemm_resident<K0C>(th, tl, X, lane, acc);
+    }
+    RBL_NSTAMP();  // 2: L0 gemm
+    write_y(m.inv_scale[0], prm);
+    RBL_NSTAMP();  // 3
+    epilogue_rows(prm);
+    RBL_NSTAMP();  // 4: L0 epilogue
+
+    // -------------------------------------------------------------- hidden layer, weights from registers
+    zero_acc();
+    gemm_resident<kKS>(w1h, w1l, X, lane, acc);
+    RBL_NSTAMP();  // 5: hidden gemm
+    write_y(m.inv_scale[1], prm + 768);
+    RBL_NSTAMP();  // 6
+    epilogue_rows(prm + 768);
+    RBL_NSTAMP();  // 7: hidden epilogue
+
+    // -------------------------------------------------------------- output layer: wave = (row tile, k half)
+    for (int ot = 0; ot < m.out_tiles; ++ot) {
+      const int rt = wave & 3, kh = wave >> 2;
+      const f32x4* wo = reinterpret_cast<const f32x4*>(m.wo) + (size_t)ot * kWoF4;
+      Frag wh[4], wl[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (ot == 0) {
+          wh[s].v = Wo[((kh * 4 + s) * 2 + 0) * 64 + lane];
+          wl[s].v = Wo[((kh * 4 + s) * 2 + 1) * 64 + lane];
+        } else {
+          wh[s].v = wo[((kh * 4 + s) * 2 + 0) * 64 + lane];
+          wl[s].v = wo[((kh * 4 + s) * 2 + 1) * 64 + lane];
+        }
+      }
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int ks = kh * 4 + s;
+        Frag xh, xl;
+        xh.v = X[((ks * 2 + 0) * kRT + rt) * 64 + lane];
+        xl.v = X[((ks * 2 + 1) * kRT + rt) * 64 + lane];
+        a2 = RBL_MFMA(wl[s].h, xh.h, a2);
+        a3 = RBL_MFMA(wh[s].h, xl.h, a3);
+        a1 = RBL_MFMA(wh[s].h, xh.h, a1);
+      }
+      const f32x4 o = a1 + (a2 + a3);
+      if (ot > 0) __syncthreads();  // the previous tile's partials have been consumed
+      if (kh == 1) P[rt * 64 + lane] = o;
+      __syncthreads();
+      if (kh == 0) {
+        const int64_t row = row0 + rt * 16 + j;
+        const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[2];
+        if (row < rows) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = ot * 16 + 4 * g + r;
+            if (i < m.n_out) out[row * m.n_out + i] = r4[r] + (ot == 0 ? bout0[r] : m.b_out[i]);
+          }
+        }
+      }
+    }
+    park_queries();
+    __syncthreads();  // X, P and the parked queries change hands
+    RBL_NSTAMP();     // 8: output layer
+    dbg = nullptr;    // stamps describe the first group of each workgroup
+  }
+#undef RBL_NSTAMP
+}
+
+}  // namespace
+
+bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out) {
+  return n_layers == 2 && n_hidden == 256 && n_in >= 1 && n_in <= 128 && n_out >= 1 && n_out <= 64;
+}
+
+void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
+  static int n_cu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("launch_mlp_resident: no current device");
+  if (dev < 64 && n_cu[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n_cu[dev] = v;
+  }
+  const int cus = dev < 64 ? n_cu[dev] : 256;
+  const int n_groups = (int)((rows + kRows - 1) / kRows);
+  const int grid = n_groups < cus ? n_groups : cus;
+#define RBL_RES(K0C_)                                                                                              \
+  do {                                                                                                             \
+    if (m.use_ln)                                                                                                  \
+      hipLaunchKernelGGL((mlp_resident_kernel<K0C_, true>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries,  \
+                         rows, out, n_groups);                                                                     \
+    else                                                                                                           \
+      hipLaunchKernelGGL((mlp_resident_kernel<K0C_, false>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
+                         rows, out, n_groups);                                                                     \
+  } while (0)
+  if (m.out_tiles < 1 || m.out_tiles > 4) throw std::runtime_error("launch_mlp_resident: unsupported n_out");
+  switch (m.l0_chunks) {
+    case 1: RBL_RES(1); break;
+    case 2: RBL_RES(2); break;
+    case 3: RBL_RES(3); break;
+    default: RBL_RES(4); break;
+  }
+#undef RBL_RES
+}
+
+}  // namespace rbl
