@@ -1254,26 +1254,51 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
         tape[(frag * 64 + lane) * 8 + e] = part == 0 ? hi : lo;
       }
   };
+  // resident + LayerNorm: centre each dense layer over its output features (W[f][k] -= mean_f W[f][k], b -= mean(b)); the
+  // GEMM then produces y - mean(y) directly and the kernel's LayerNorm only has the variance left to compute
+  std::vector<std::vector<float>> wc(n_layers), bc(n_layers);
+  std::vector<const float*> wp(n_layers), bp(n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    const int K = l == 0 ? n_in : n_hidden;
+    wp[l] = w[l];
+    bp[l] = b[l];
+    if (resident && use_ln) {
+      wc[l].assign(w[l], w[l] + (size_t)n_hidden * K);
+      bc[l].assign(b[l], b[l] + n_hidden);
+      for (int k = 0; k < K; ++k) {
+        double mu = 0;
+        for (int f = 0; f < n_hidden; ++f) mu += w[l][(size_t)f * K + k];
+        mu /= n_hidden;
+        for (int f = 0; f < n_hidden; ++f) wc[l][(size_t)f * K + k] = (float)((double)w[l][(size_t)f * K + k] - mu);
+      }
+      double mb = 0;
+      for (int f = 0; f < n_hidden; ++f) mb += b[l][f];
+      mb /= n_hidden;
+      for (int f = 0; f < n_hidden; ++f) bc[l][f] = (float)((double)b[l][f] - mb);
+      wp[l] = wc[l].data();
+      bp[l] = bc[l].data();
+    }
+  }
   p.inv_scale.assign(n_layers + 1, 1.f);
   {
-    const float S = scale_of(w[0], (size_t)n_hidden * n_in);
+    const float S = scale_of(wp[0], (size_t)n_hidden * n_in);
     p.inv_scale[0] = 1.0f / S;
     for (int wv = 0; wv < NW; ++wv)
       for (int ks = 0; ks < ks0; ++ks)
         for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
-            put(((size_t)(wv * ks0 + ks) * OTW + ot) * 2 + part, w[0], n_in, n_hidden, n_in, 16 * (OTW * wv + ot), ks, S,
+            put(((size_t)(wv * ks0 + ks) * OTW + ot) * 2 + part, wp[0], n_in, n_hidden, n_in, 16 * (OTW * wv + ot), ks, S,
                 part);
   }
   const size_t frag_wh = p.off_wh / frag_f, frag_wo = p.off_wo / frag_f;
   for (int l = 1; l < n_layers; ++l) {
-    const float S = scale_of(w[l], (size_t)n_hidden * n_hidden);
+    const float S = scale_of(wp[l], (size_t)n_hidden * n_hidden);
     p.inv_scale[l] = 1.0f / S;
     for (int wv = 0; wv < NW; ++wv)
       for (int ks = 0; ks < KS; ++ks)
         for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
-            put(frag_wh + ((((size_t)(l - 1) * NW + wv) * KS + ks) * OTW + ot) * 2 + part, w[l], n_hidden, n_hidden,
+            put(frag_wh + ((((size_t)(l - 1) * NW + wv) * KS + ks) * OTW + ot) * 2 + part, wp[l], n_hidden, n_hidden,
                 n_hidden, 16 * (OTW * wv + ot), ks, S, part, post);
   }
   {
@@ -1286,7 +1311,7 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
   }
   for (int l = 0; l < n_layers; ++l)
     for (int i = 0; i < n_hidden; ++i) {
-      p.blob[p.off_bias + (size_t)l * n_hidden + i] = b[l][i];
+      p.blob[p.off_bias + (size_t)l * n_hidden + i] = bp[l][i];
       p.blob[p.off_lnw + (size_t)l * n_hidden + i] = use_ln ? ln_w[l][i] : 1.f;
       p.blob[p.off_lnb + (size_t)l * n_hidden + i] = use_ln ? (float)((double)ln_b[l][i] * pre) : 0.f;
     }

@@ -52,17 +52,18 @@ constexpr int kImageBytes = kRows * kYStride * 4;
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 
-// -GELU(sqrt2 z) / sqrt2 for two elements (see the header; the sign goes into the next layer's weights too)
+// -GELU(sqrt2 z) / sqrt2 = t erfc(t) / 2 - max(z, 0), t = min(|z|, 4), for two elements.  t erfc(t) / 2 is evaluated as
+// t 2^(t R(t) - 1) with R a degree-5 polynomial fitted (minimax on [0, 4], scripts/fit_gelu.py) to THAT product: max error
+// 1.06e-7 in f32 arithmetic, i.e. 1.5e-7 on GELU itself; erfc(4) = 1.5e-8, so the clamp costs nothing.  13 VALU
+// instructions per pair: 2 v_min (|z| clamp), 7 v_pk_fma, 2 v_exp, 2 v_min (-relu).
 __device__ __forceinline__ f32x2 gelu_z(f32x2 z) {
   const f32x2 t = __builtin_elementwise_min(__builtin_elementwise_abs(z), splat2(4.0f));
-  f32x2 r = splat2(-4.535757872e-05f);
-  r = fma2(r, t, splat2(4.454992795e-04f));
-  r = fma2(r, t, splat2(-1.489414726e-03f));
-  r = fma2(r, t, splat2(-7.746730062e-04f));
-  r = fma2(r, t, splat2(2.825371816e-02f));
-  r = fma2(r, t, splat2(-1.484816315e-01f));
-  r = fma2(r, t, splat2(-9.184163899e-01f));
-  r = fma2(r, t, splat2(-1.627908593e+00f));
+  f32x2 r = splat2(2.635702834e-04f);
+  r = fma2(r, t, splat2(-4.330650409e-03f));
+  r = fma2(r, t, splat2(3.223223815e-02f));
+  r = fma2(r, t, splat2(-1.509066050e-01f));
+  r = fma2(r, t, splat2(-9.176831254e-01f));
+  r = fma2(r, t, splat2(-1.627991484e+00f));
   r = fma2(r, t, splat2(-1.0f));
   const f32x2 e = f32x2{__builtin_amdgcn_exp2f(r[0]), __builtin_amdgcn_exp2f(r[1])};
   return fma2(t, e, __builtin_elementwise_min(-z, splat2(0.0f)));
@@ -90,6 +91,12 @@ __device__ __forceinline__ float row_sum8(float s) {
   s += c;
   asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s), "=&v"(c));
   return s + c;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for the query
+// prefetch of the next group and for the output stores of this one at every phase boundary.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 #define RBL_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_f16((A_), (B_), (C_), 0, 0, 0)
@@ -134,7 +141,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
                                                                     int64_t rows, float* __restrict__ out, int n_groups) {
   constexpr int kStageFloats = kRows * 32 * K0C;
   constexpr int NQ = (kStageFloats + kWaves * 64 - 1) / (kWaves * 64);
-  constexpr int kParamFloats = 2 * 3 * 256;  // per layer: bias, gamma, beta / sqrt2
+  constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
   constexpr int kWoF4 = kKS * 2 * 64;        // one output tile's weight fragments (16 KB)
   __shared__ __align__(16) unsigned char smem[kImageBytes + kStageFloats * 4 + kRT * 64 * 16 + kParamFloats * 4 + kWoF4 * 16];
   float* Y = reinterpret_cast<float*>(smem);                                   // [64][260] f32 pre-activations
@@ -186,10 +193,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     }
   }
   for (int i = tid; i < kWoF4; i += kWaves * 64) Wo[i] = reinterpret_cast<const f32x4*>(m.wo)[i];
-
-  f32x4 bout0;  // output bias of tile 0, features 4g .. 4g+3
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bout0[r] = 4 * g + r < m.n_out ? m.b_out[4 * g + r] : 0.f;
+  if (tid < 64) prm[2 * 3 * 256 + tid] = tid < m.n_out ? m.b_out[tid] : 0.f;
 
   // raw query rows of group `grp` -> registers (coalesced; rows past the end read as zero)
   float qn[NQ];
@@ -219,7 +223,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
   // pre-activations (+ bias) of this wave's 32 features -> row-major image; everybody must be done READING X first
   auto write_y = [&](float inv_s, const float* bias) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot) {
       const int f0 = 16 * kOTW * wave + 16 * ot + 4 * g;
@@ -228,7 +232,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       for (int rt = 0; rt < kRT; ++rt)
         *reinterpret_cast<f32x4*>(&Y[(rt * 16 + j) * kYStride + f0]) = acc[ot][rt] * inv_s + b4;
     }
-    __syncthreads();
+    lds_barrier();
   };
 
   // LayerNorm + GELU, row-parallel (thread = row, 8 x 4 features {32 i + 4 fg + r}), result written back over the same
@@ -239,21 +243,18 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     f32x4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(&Y[row * kYStride + 32 * i + 4 * fg]);
-    __syncthreads();  // the image is about to be overwritten by the next layer's operands
+    lds_barrier();  // the image is about to be overwritten by the next layer's operands
     constexpr float kC = 0.70710678118654752440f;
     float rs = kC;
     if constexpr (LN) {
-      f32x2 s2 = splat2(0.f);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s2 += f32x2{v[i][0], v[i][1]} + f32x2{v[i][2], v[i][3]};
-      const float mean = row_sum8(s2[0] + s2[1]) * (1.0f / 256.0f);
+      // the weights and biases of a LayerNorm'ed layer are centred over the output features on the host (pack_mlp), so
+      // the pre-activations arrive with their row mean already removed: only the variance is left to compute
       f32x2 q2 = splat2(0.f);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const f32x2 d0 = f32x2{v[i][0], v[i][1]} - splat2(mean), d1 = f32x2{v[i][2], v[i][3]} - splat2(mean);
+        const f32x2 d0 = f32x2{v[i][0], v[i][1]}, d1 = f32x2{v[i][2], v[i][3]};
         q2 = fma2(d0, d0, q2);
         q2 = fma2(d1, d1, q2);
-        v[i] = f32x4{d0[0], d0[1], d1[0], d1[1]};
       }
       const float var = row_sum8(q2[0] + q2[1]) * (1.0f / 256.0f) + m.ln_eps;
       float y0 = __builtin_amdgcn_rsqf(var);  // v_rsq_f32 (1 ulp) + one Newton step
@@ -278,13 +279,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       X8[(((i * 2 + 0) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, hh);
       X8[(((i * 2 + 1) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, ll);
     }
-    __syncthreads();
+    lds_barrier();
   };
 
   // ---------------------------------------------------------------- prologue: first group's queries -> LDS
   fetch_queries(blockIdx.x);
   park_queries();
-  __syncthreads();
+  lds_barrier();
 
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int64_t row0 = (int64_t)grp * kRows;
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         X[((ks * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
       }
     }
-    __syncthreads();
+    lds_barrier();
     fetch_queries(grp + gridDim.x);  // in flight until the end of this group
     RBL_NSTAMP();  // 1: staged
 
@@ -371,23 +372,31 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         a1 = RBL_MFMA(wh[s].h, xh.h, a1);
       }
       const f32x4 o = a1 + (a2 + a3);
-      if (ot > 0) __syncthreads();  // the previous tile's partials have been consumed
+      if (dbg && tid == 0) dbg[9] = (long long)clock64();
+      if (ot > 0) lds_barrier();  // the previous tile's partials have been consumed
       if (kh == 1) P[rt * 64 + lane] = o;
-      __syncthreads();
+      lds_barrier();
+      if (dbg && tid == 0) dbg[10] = (long long)clock64();
       if (kh == 0) {
-        const int64_t row = row0 + rt * 16 + j;
-        const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[2];
-        if (row < rows) {
+        // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
+        int r_in = rt * 16 + j, col = 4 * g;
+        const int n_out = m.n_out;
+        asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
+        const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
+        float* og = out + row0 * n_out;
+        const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + ot * 16 + col);
+        if (r_in < rows_here) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int i = ot * 16 + 4 * g + r;
-            if (i < m.n_out) out[row * m.n_out + i] = r4[r] + (ot == 0 ? bout0[r] : m.b_out[i]);
+            const int i = ot * 16 + col + r;
+            if (i < n_out) og[r_in * n_out + i] = r4[r];
           }
         }
       }
     }
+    if (dbg && tid == 0) dbg[11] = (long long)clock64();
     park_queries();
-    __syncthreads();  // X, P and the parked queries change hands
+    lds_barrier();  // X, P and the parked queries change hands
     RBL_NSTAMP();     // 8: output layer
     dbg = nullptr;    // stamps describe the first group of each workgroup
   }

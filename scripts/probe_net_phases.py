@@ -17,4 +17,6 @@ names = ["stage queries", "L0 gemm", "L0 y write", "L0 epilogue", "H gemm", "H y
 dt = np.diff(d[:, :9], axis=1)
 print(f"rows={rows}: per-phase cycles over the first {n} workgroups (median, p90)")
 for i, nm in enumerate(names): print(f"  {nm:14s} {np.median(dt[:, i]):8.0f} {np.percentile(dt[:, i], 90):8.0f}")
+if d.shape[1] > 11 and d[:, 9:12].any():
+    print("  output detail (from hidden-epilogue end): mfma done %d, partial barrier %d, stores issued %d, end %d" % tuple(np.median(d[:, k] - d[:, 7]) for k in (9, 10, 11, 8)))
 print("  total          %8.0f %8.0f" % (np.median(d[:, 8] - d[:, 0]), np.percentile(d[:, 8] - d[:, 0], 90)))
