@@ -1243,11 +1243,14 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
     if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
     return std::ldexp(1.0f, (int)std::floor(std::log2(8192.0f / mx)));
   };
+  // perm: the k order inside a 32-wide k-step is (tile, lane group, r) = the order in which the resident kernel's
+  // in-register epilogue leaves the previous layer's activations (net_resident_kernel.hip: epilogue_regs)
   auto put = [&](size_t frag, const float* W, int ld, int n_rows, int n_cols, int i0, int ks, float S, int part,
-                 double fold = 1.0) {
+                 double fold = 1.0, bool perm = false) {
     for (int lane = 0; lane < 64; ++lane)
       for (int e = 0; e < 8; ++e) {
-        const int i = i0 + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + e;
+        const int i = i0 + (lane & 15);
+        const int k = perm ? 32 * ks + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3) : 32 * ks + 8 * (lane >> 4) + e;
         const float v = (i < n_rows && k < n_cols) ? (float)((double)W[(size_t)i * ld + k] * S * fold) : 0.f;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)((v - (float)hi) * lo_scale);
@@ -1299,7 +1302,7 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
         for (int ot = 0; ot < OTW; ++ot)
           for (int part = 0; part < 2; ++part)
             put(frag_wh + ((((size_t)(l - 1) * NW + wv) * KS + ks) * OTW + ot) * 2 + part, wp[l], n_hidden, n_hidden,
-                n_hidden, 16 * (OTW * wv + ot), ks, S, part, post);
+                n_hidden, 16 * (OTW * wv + ot), ks, S, part, post, resident);
   }
   {
     const float S = scale_of(w_out, (size_t)n_out * n_hidden);
@@ -1307,7 +1310,7 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
     for (int ot = 0; ot < p.out_tiles; ++ot)
       for (int ks = 0; ks < KS; ++ks)
         for (int part = 0; part < 2; ++part)
-          put(frag_wo + ((size_t)ot * KS + ks) * 2 + part, w_out, n_hidden, n_out, n_hidden, 16 * ot, ks, S, part, post);
+          put(frag_wo + ((size_t)ot * KS + ks) * 2 + part, w_out, n_hidden, n_out, n_hidden, 16 * ot, ks, S, part, post, resident);
   }
   for (int l = 0; l < n_layers; ++l)
     for (int i = 0; i < n_hidden; ++i) {

@@ -46,8 +46,8 @@ union Frag {
 };
 
 constexpr int kRows = 64, kRT = 4, kKS = 8, kOTW = 2, kWaves = 8;
-constexpr int kYStride = 260;  // f32 per image row (+4: conflict-free 16-byte column writes)
-constexpr int kImageBytes = kRows * kYStride * 4;
+constexpr int kImageBytes = kKS * 2 * kRT * 64 * 16;  // activations of one group as f16x2 B fragments (64 KB)
+constexpr int kStatBytes = kRows * kWaves * 4;        // per-row, per-wave partial sums of squares (LayerNorm)
 
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
@@ -143,12 +143,11 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   constexpr int NQ = (kStageFloats + kWaves * 64 - 1) / (kWaves * 64);
   constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
   constexpr int kWoF4 = kKS * 2 * 64;        // one output tile's weight fragments (16 KB)
-  __shared__ __align__(16) unsigned char smem[kImageBytes + kStageFloats * 4 + kRT * 64 * 16 + kParamFloats * 4 + kWoF4 * 16];
-  float* Y = reinterpret_cast<float*>(smem);                                   // [64][260] f32 pre-activations
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kStageFloats * 4 + kRT * 64 * 16 + kParamFloats * 4 + kWoF4 * 16];
   f32x4* X = reinterpret_cast<f32x4*>(smem);                                   // [ks][hi,lo][row tile][lane] B fragments
-  unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
-  float* qs = reinterpret_cast<float*>(smem + kImageBytes);                    // [64][n_in] raw queries of the next group
-  f32x4* P = reinterpret_cast<f32x4*>(smem + kImageBytes + kStageFloats * 4);  // [row tile][lane] output partials
+  float* S = reinterpret_cast<float*>(smem + kImageBytes);                     // [row][wave] sums of squares
+  float* qs = S + kRows * kWaves;                                              // [64][n_in] raw queries of the next group
+  f32x4* P = reinterpret_cast<f32x4*>(qs + kStageFloats);                      // [row tile][lane] output partials
   float* prm = reinterpret_cast<float*>(P + kRT * 64);                         // [layer][bias, gamma, beta'][256]
   f32x4* Wo = reinterpret_cast<f32x4*>(prm + kParamFloats);                    // [ks][hi,lo][lane] of output tile 0
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,63 +220,83 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       for (int rt = 0; rt < kRT; ++rt) acc[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // pre-activations (+ bias) of this wave's 32 features -> row-major image; everybody must be done READING X first
-  auto write_y = [&](float inv_s, const float* bias) {
-    lds_barrier();
+  // bias + LayerNorm + GELU on the accumulators, in place, and straight into the next layer's B fragments.
+  // D layout of the MFMA: lane (j = lane & 15, g = lane >> 4) holds, for row tile rt, features 4g .. 4g+3 of each of this
+  // wave's two 16-feature tiles: 8 values = exactly one 16-byte B fragment of k-step `wave` of the next layer, provided
+  // that layer's weights are packed with k running as (tile, g, r) inside the k-step -- which is what pack_mlp does for
+  // tile 5.  So there is no f32 image and no transposition: the only thing the waves exchange per layer is the row
+  // variance (one float per row and wave).  The first barrier doubles as "everybody is done reading the old X".
+  auto epilogue_regs = [&](float inv_s, const float* pl) {
+    f32x4 d[kOTW][kRT];
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot) {
-      const int f0 = 16 * kOTW * wave + 16 * ot + 4 * g;
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + f0);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < kRT; ++rt)
-        *reinterpret_cast<f32x4*>(&Y[(rt * 16 + j) * kYStride + f0]) = acc[ot][rt] * inv_s + b4;
+      for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = acc[ot][rt] * inv_s + b4;
     }
-    lds_barrier();
-  };
-
-  // LayerNorm + GELU, row-parallel (thread = row, 8 x 4 features {32 i + 4 fg + r}), result written back over the same
-  // bytes as f16x2 B fragments.  Lane -> (row, fg) mapping as in net_kernels.hip (conflict-free 8-byte fragment writes).
-  auto epilogue_rows = [&](const float* pl) {
-    const int fg = (lane & 1) | ((lane >> 4) << 1);
-    const int row = wave * 8 + ((lane >> 1) & 7);
-    f32x4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(&Y[row * kYStride + 32 * i + 4 * fg]);
-    lds_barrier();  // the image is about to be overwritten by the next layer's operands
     constexpr float kC = 0.70710678118654752440f;
-    float rs = kC;
+    float rs[kRT];
     if constexpr (LN) {
-      // the weights and biases of a LayerNorm'ed layer are centred over the output features on the host (pack_mlp), so
-      // the pre-activations arrive with their row mean already removed: only the variance is left to compute
-      f32x2 q2 = splat2(0.f);
+      // weights and biases are centred over the output features on the host: d has zero row mean, only the variance is left
+      float q[kRT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const f32x2 d0 = f32x2{v[i][0], v[i][1]}, d1 = f32x2{v[i][2], v[i][3]};
-        q2 = fma2(d0, d0, q2);
-        q2 = fma2(d1, d1, q2);
+      for (int rt = 0; rt < kRT; ++rt) {
+        f32x2 q2 = splat2(0.f);
+#pragma unroll
+        for (int ot = 0; ot < kOTW; ++ot) {
+          const f32x2 lo = f32x2{d[ot][rt][0], d[ot][rt][1]}, hi = f32x2{d[ot][rt][2], d[ot][rt][3]};
+          q2 = fma2(lo, lo, q2);
+          q2 = fma2(hi, hi, q2);
+        }
+        q[rt] = q2[0] + q2[1];
       }
-      const float var = row_sum8(q2[0] + q2[1]) * (1.0f / 256.0f) + m.ln_eps;
-      float y0 = __builtin_amdgcn_rsqf(var);  // v_rsq_f32 (1 ulp) + one Newton step
-      y0 = y0 * __builtin_fmaf(-0.5f * var, y0 * y0, 1.5f);
-      rs = kC * y0;
+      // sum over the four lane groups g, all four row tiles at once: each swap + add halves two registers into one.
+      // Afterwards lane group g holds the total of row tile {0, 2, 1, 3}[g].
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(q[0]), "+v"(q[1]));
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(q[2]), "+v"(q[3]));
+      float a01 = q[0] + q[1], a23 = q[2] + q[3];
+      asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a01), "+v"(a23));
+      const int rtp = ((g & 1) << 1) | (g >> 1);
+      S[(rtp * 16 + j) * kWaves + wave] = a01 + a23;
+      lds_barrier();
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves]);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves + 4]);
+        const f32x4 t = s0 + s1;
+        const float var = ((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f) + m.ln_eps;
+        float y0 = __builtin_amdgcn_rsqf(var);  // v_rsq_f32 (1 ulp) + one Newton step
+        y0 = y0 * __builtin_fmaf(-0.5f * var, y0 * y0, 1.5f);
+        rs[rt] = kC * y0;
+      }
+    } else {
+      lds_barrier();
+#pragma unroll
+      for (int rt = 0; rt < kRT; ++rt) rs[rt] = kC;
     }
-    const int rt = row >> 4, lane2 = (fg >> 1) * 16 + (row & 15);
+    f32x4 g4[kOTW], o4[kOTW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(pl + 256 + 32 * i + 4 * fg);
-      const f32x4 o4 = *reinterpret_cast<const f32x4*>(pl + 512 + 32 * i + 4 * fg);  // beta / sqrt2
-      f32x2 y[2];
+    for (int ot = 0; ot < kOTW; ++ot) {
+      g4[ot] = *reinterpret_cast<const f32x4*>(pl + 256 + 32 * wave + 16 * ot + 4 * g);
+      o4[ot] = *reinterpret_cast<const f32x4*>(pl + 512 + 32 * wave + 16 * ot + 4 * g);  // beta / sqrt2
+    }
 #pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) {
-        const f32x2 a = f32x2{g4[2 * h2], g4[2 * h2 + 1]} * splat2(rs);
-        y[h2] = gelu_z(fma2(f32x2{v[i][2 * h2], v[i][2 * h2 + 1]}, a, f32x2{o4[2 * h2], o4[2 * h2 + 1]}));
-      }
-      f16x2 h0, l0, h1, l1;
-      split2(y[0][0], y[0][1], &h0, &l0);
-      split2(y[1][0], y[1][1], &h1, &l1);
-      const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
-      X8[(((i * 2 + 0) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, hh);
-      X8[(((i * 2 + 1) * kRT + rt) * 64 + lane2) * 2 + (fg & 1)] = __builtin_bit_cast(unsigned long long, ll);
+    for (int rt = 0; rt < kRT; ++rt) {
+      f16x2 h[4], l[4];
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const f32x2 a = f32x2{g4[ot][2 * h2], g4[ot][2 * h2 + 1]} * splat2(rs[rt]);
+          const f32x2 y = gelu_z(fma2(f32x2{d[ot][rt][2 * h2], d[ot][rt][2 * h2 + 1]}, a,
+                                      f32x2{o4[ot][2 * h2], o4[ot][2 * h2 + 1]}));
+          split2(y[0], y[1], &h[2 * ot + h2], &l[2 * ot + h2]);
+        }
+      Frag fh, fl;
+      fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
+      fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
+      X[((wave * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
+      X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
     }
     lds_barrier();
   };
@@ -331,18 +350,16 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       gemm_resident<K0C>(th, tl, X, lane, acc);
     }
     RBL_NSTAMP();  // 2: L0 gemm
-    write_y(m.inv_scale[0], prm);
     RBL_NSTAMP();  // 3
-    epilogue_rows(prm);
+    epilogue_regs(m.inv_scale[0], prm);
     RBL_NSTAMP();  // 4: L0 epilogue
 
     // -------------------------------------------------------------- hidden layer, weights from registers
     zero_acc();
     gemm_resident<kKS>(w1h, w1l, X, lane, acc);
     RBL_NSTAMP();  // 5: hidden gemm
-    write_y(m.inv_scale[1], prm + 768);
     RBL_NSTAMP();  // 6
-    epilogue_rows(prm + 768);
+    epilogue_regs(m.inv_scale[1], prm + 768);
     RBL_NSTAMP();  // 7: hidden epilogue
 
     // -------------------------------------------------------------- output layer: wave = (row tile, k half)
