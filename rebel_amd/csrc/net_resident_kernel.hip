@@ -27,6 +27,7 @@
 // Supported shape: n_layers == 2 (one hidden layer, the reference's configuration liars_sp.yaml:28-33), n_hidden == 256,
 // n_in <= 128, n_out <= 64.  Anything else stays on the tile-3 kernel.
 #include <stdexcept>
+#include <type_traits>
 
 #include "net_kernels.h"
 
@@ -139,21 +140,20 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NKS][kOTW], const
 template <int K0C, bool LN>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups) {
-  constexpr int kStageFloats = kRows * 32 * K0C;
-  constexpr int NQ = (kStageFloats + kWaves * 64 - 1) / (kWaves * 64);
   constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
-  constexpr int kWoF4 = kKS * 2 * 64;        // one output tile's weight fragments (16 KB)
-  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kStageFloats * 4 + kRT * 64 * 16 + kParamFloats * 4 + kWoF4 * 16];
-  f32x4* X = reinterpret_cast<f32x4*>(smem);                                   // [ks][hi,lo][row tile][lane] B fragments
-  float* S = reinterpret_cast<float*>(smem + kImageBytes);                     // [row][wave] sums of squares
-  float* qs = S + kRows * kWaves;                                              // [64][n_in] raw queries of the next group
-  f32x4* P = reinterpret_cast<f32x4*>(qs + kStageFloats);                      // [row tile][lane] output partials
-  float* prm = reinterpret_cast<float*>(P + kRT * 64);                         // [layer][bias, gamma, beta'][256]
-  f32x4* Wo = reinterpret_cast<f32x4*>(prm + kParamFloats);                    // [ks][hi,lo][lane] of output tile 0
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, g = lane >> 4;
-  const int n_in = m.n_in, q_elems = kRows * n_in;
+  constexpr int kWoF4 = kKS * 2 * 64;             // one output tile's weight fragments (16 KB)
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4];
+  f32x4* X = reinterpret_cast<f32x4*>(smem);                 // [ks][hi,lo][row tile][lane] B fragments
+  unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
+  float* S = reinterpret_cast<float*>(smem + kImageBytes);   // [row][wave] sums of squares
+  f32x4* P = reinterpret_cast<f32x4*>(S + kRows * kWaves);   // [wave][row tile][lane] partial outputs (k slice of a wave)
+  float* prm = reinterpret_cast<float*>(P + kWaves * kRT * 64);  // [layer][bias, gamma, beta'][256], output bias
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
+  const int lane0 = tid & 63;
+  int lane = lane0, j = lane0 & 15, g = lane0 >> 4;
+  const int n_in = m.n_in;
   long long* dbg = m.dbg && blockIdx.x < 1024 ? m.dbg + (size_t)blockIdx.x * 16 : nullptr;
+  long long* const dbg_end = dbg;
   int dbg_k = 0;
 #define RBL_NSTAMP()                                              \
   do {                                                            \
@@ -163,14 +163,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
   // ---------------------------------------------------------------- this wave's weights, resident for the whole launch
   const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
-  Frag w0h[1][kOTW], w0l[1][kOTW];
-  if constexpr (K0C == 1) {
-#pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) {
-      w0h[0][ot].v = blob[((size_t)wave * kOTW + ot) * 2 * 64 + lane];
-      w0l[0][ot].v = blob[(((size_t)wave * kOTW + ot) * 2 + 1) * 64 + lane];
-    }
-  }
   Frag w1h[kKS][kOTW], w1l[kKS][kOTW];
   {
     const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
@@ -191,25 +183,24 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       prm[(l * 3 + 2) * 256 + i] = m.ln_b[l * 256 + i];
     }
   }
-  for (int i = tid; i < kWoF4; i += kWaves * 64) Wo[i] = reinterpret_cast<const f32x4*>(m.wo)[i];
   if (tid < 64) prm[2 * 3 * 256 + tid] = tid < m.n_out ? m.b_out[tid] : 0.f;
 
-  // raw query rows of group `grp` -> registers (coalesced; rows past the end read as zero)
-  float qn[NQ];
+  // Query rows of a group, fetched straight in B-fragment order: thread (row tile = wave >> 1, half = wave & 1, j, g)
+  // reads k = 32 ks + 8 g + 4 half + {0..3} of row 16 rt + j (a row is 4 n_in contiguous bytes; the 8 threads of a
+  // row cover it in 16-byte pieces).  The loads for group n+1 are issued right after group n is staged and stay in
+  // flight until the next staging step.
+  float qn[K0C][4];
   auto fetch_queries = [&](int grp) {
-    const int64_t base = (int64_t)grp * q_elems, total = rows * n_in;
+    const int64_t row = (int64_t)grp * kRows + (wave >> 1) * 16 + j;
+    const bool ok = grp < n_groups && row < rows;
+    const float* q = queries + (ok ? row : 0) * n_in;
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int e = i * (kWaves * 64) + tid;
-      qn[i] = (grp < n_groups && e < q_elems && base + e < total) ? queries[base + e] : 0.f;
-    }
-  };
-  auto park_queries = [&]() {
+    for (int ks = 0; ks < K0C; ++ks)
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int e = i * (kWaves * 64) + tid;
-      if (e < q_elems) qs[e] = qn[i];
-    }
+      for (int e = 0; e < 4; ++e) {
+        const int k = 32 * ks + 8 * g + 4 * (wave & 1) + e;
+        qn[ks][e] = (ok && k < n_in) ? q[k] : 0.f;
+      }
   };
 
   f32x4 acc[kOTW][kRT];
@@ -226,7 +217,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // that layer's weights are packed with k running as (tile, g, r) inside the k-step -- which is what pack_mlp does for
   // tile 5.  So there is no f32 image and no transposition: the only thing the waves exchange per layer is the row
   // variance (one float per row and wave).  The first barrier doubles as "everybody is done reading the old X".
-  auto epilogue_regs = [&](float inv_s, const float* pl) {
+  auto epilogue_regs = [&](auto last_tag, float inv_s, const float* pl) {
+    constexpr bool kLast = decltype(last_tag)::value;  // feeds the output layer: tile 0 straight from registers
+    Frag woh, wol;  // output layer, tile 0, k-step `wave`: 2 KB from L2 per wave and group, requested here, used at the end
+    if constexpr (kLast) {
+      woh.v = reinterpret_cast<const f32x4*>(m.wo)[(wave * 2 + 0) * 64 + lane];
+      wol.v = reinterpret_cast<const f32x4*>(m.wo)[(wave * 2 + 1) * 64 + lane];
+    }
     f32x4 d[kOTW][kRT];
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot) {
@@ -295,63 +292,71 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       Frag fh, fl;
       fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
       fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
-      X[((wave * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
-      X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
+      if (!kLast || m.out_tiles > 1) {
+        X[((wave * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
+        X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
+      }
+      if constexpr (kLast) {  // this wave's 32-wide k slice of the output layer, summed over the waves below
+        f32x4 o = RBL_MFMA(wol.h, fh.h, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        o = RBL_MFMA(woh.h, fl.h, o);
+        o = RBL_MFMA(woh.h, fh.h, o);
+        P[(wave * kRT + rt) * 64 + lane] = o;
+      }
     }
     lds_barrier();
   };
 
-  // ---------------------------------------------------------------- prologue: first group's queries -> LDS
+  // Layer-0 weights of this wave (4 KB per 32-wide k chunk) are NOT kept across the epilogues: next to the hidden layer's
+  // 128 VGPRs they pushed the kernel into scratch spills.  They are re-read from L2 once per group, requested as soon as the
+  // registers are free again (after the last epilogue of the previous group), so the round trip is off the critical path.
+  Frag th[K0C][kOTW], tl[K0C][kOTW];
+  auto fetch_w0 = [&]() {
+    const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64;
+    asm volatile("" : "+s"(w0));  // a fresh load every group (the values are loop invariant; hoisting = residency)
+#pragma unroll
+    for (int ks = 0; ks < K0C; ++ks)
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot) {
+        th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+        tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+      }
+  };
+  fetch_w0();
   fetch_queries(blockIdx.x);
-  park_queries();
-  lds_barrier();
+  __syncthreads();  // parameter copies visible
 
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
     const int64_t row0 = (int64_t)grp * kRows;
+    // lane-derived indices are re-derived every group: hoisted out of the loop, the dozens of LDS / global addresses built
+    // from them stay live across all phases and push the 256-VGPR budget (128 of it weights) into scratch spills
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    j = lane & 15;
+    g = lane >> 4;
     RBL_NSTAMP();  // 0
-    // -------------------------------------------------------------- parked queries -> f16x2 B fragments
-    if (tid < kRT * 64) {
-      const int rt = tid >> 6;
-      const float* qrow = qs + (rt * 16 + j) * n_in;
+    // -------------------------------------------------------------- fetched queries -> f16x2 B fragments (8 bytes each)
+    {
+      const int rt = wave >> 1, half = wave & 1;
 #pragma unroll
       for (int ks = 0; ks < K0C; ++ks) {
-        f16x2 h[4], l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = 32 * ks + 8 * g + 2 * e;
-          const float q0 = k < n_in ? qrow[k] : 0.f, q1 = k + 1 < n_in ? qrow[k + 1] : 0.f;
-          split2(q0, q1, &h[e], &l[e]);
-        }
-        Frag fh, fl;
-        fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
-        fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
-        X[((ks * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
-        X[((ks * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
+        f16x2 h0, l0, h1, l1;
+        split2(qn[ks][0], qn[ks][1], &h0, &l0);
+        split2(qn[ks][2], qn[ks][3], &h1, &l1);
+        const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
+        X8[(((ks * 2 + 0) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, hh);
+        X8[(((ks * 2 + 1) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, ll);
       }
     }
     lds_barrier();
-    fetch_queries(grp + gridDim.x);  // in flight until the end of this group
+    fetch_queries(grp + gridDim.x);  // in flight until the next group is staged
     RBL_NSTAMP();  // 1: staged
 
     // -------------------------------------------------------------- layer 0
     zero_acc();
-    if constexpr (K0C == 1) {
-      gemm_resident<1>(w0h, w0l, X, lane, acc);
-    } else {
-      const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64;
-      Frag th[K0C][kOTW], tl[K0C][kOTW];
-#pragma unroll
-      for (int ks = 0; ks < K0C; ++ks)
-#pragma unroll
-        for (int ot = 0; ot < kOTW; ++ot) {
-          th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-          tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
-        }
-      gemm_resident<K0C>(th, tl, X, lane, acc);
-    }
+    gemm_resident<K0C>(th, tl, X, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     RBL_NSTAMP();  // 3
-    epilogue_regs(m.inv_scale[0], prm);
+    epilogue_regs(std::false_type{}, m.inv_scale[0], prm);
     RBL_NSTAMP();  // 4: L0 epilogue
 
     // -------------------------------------------------------------- hidden layer, weights from registers
@@ -359,46 +364,54 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     gemm_resident<kKS>(w1h, w1l, X, lane, acc);
     RBL_NSTAMP();  // 5: hidden gemm
     RBL_NSTAMP();  // 6
-    epilogue_regs(m.inv_scale[1], prm + 768);
-    RBL_NSTAMP();  // 7: hidden epilogue
+    epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
+    RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
+    if (grp + (int)gridDim.x < n_groups) fetch_w0();
 
-    // -------------------------------------------------------------- output layer: wave = (row tile, k half)
-    for (int ot = 0; ot < m.out_tiles; ++ot) {
+    // -------------------------------------------------------------- output tile 0: sum the 8 k slices, waves 0-3
+    if (wave < kRT) {
+      const int rt = wave;
+      f32x4 o = P[(0 * kRT + rt) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w) o += P[(w * kRT + rt) * 64 + lane];
+      // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
+      int r_in = rt * 16 + j, col = 4 * g;
+      const int n_out = m.n_out;
+      asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
+      const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
+      float* og = out + row0 * n_out;
+      const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
+      if (r_in < rows_here) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+      }
+    }
+    // -------------------------------------------------------------- further output tiles (n_out > 16): from the X image
+    for (int ot = 1; ot < m.out_tiles; ++ot) {
       const int rt = wave & 3, kh = wave >> 2;
       const f32x4* wo = reinterpret_cast<const f32x4*>(m.wo) + (size_t)ot * kWoF4;
-      Frag wh[4], wl[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (ot == 0) {
-          wh[s].v = Wo[((kh * 4 + s) * 2 + 0) * 64 + lane];
-          wl[s].v = Wo[((kh * 4 + s) * 2 + 1) * 64 + lane];
-        } else {
-          wh[s].v = wo[((kh * 4 + s) * 2 + 0) * 64 + lane];
-          wl[s].v = wo[((kh * 4 + s) * 2 + 1) * 64 + lane];
-        }
-      }
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int ks = kh * 4 + s;
-        Frag xh, xl;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int ks = kh * 4 + s4;
+        Frag wh, wl, xh, xl;
+        wh.v = wo[(ks * 2 + 0) * 64 + lane];
+        wl.v = wo[(ks * 2 + 1) * 64 + lane];
         xh.v = X[((ks * 2 + 0) * kRT + rt) * 64 + lane];
         xl.v = X[((ks * 2 + 1) * kRT + rt) * 64 + lane];
-        a2 = RBL_MFMA(wl[s].h, xh.h, a2);
-        a3 = RBL_MFMA(wh[s].h, xl.h, a3);
-        a1 = RBL_MFMA(wh[s].h, xh.h, a1);
+        a2 = RBL_MFMA(wl.h, xh.h, a2);
+        a3 = RBL_MFMA(wh.h, xl.h, a3);
+        a1 = RBL_MFMA(wh.h, xh.h, a1);
       }
       const f32x4 o = a1 + (a2 + a3);
-      if (dbg && tid == 0) dbg[9] = (long long)clock64();
-      if (ot > 0) lds_barrier();  // the previous tile's partials have been consumed
+      lds_barrier();  // the partials of the previous tile have been consumed
       if (kh == 1) P[rt * 64 + lane] = o;
       lds_barrier();
-      if (dbg && tid == 0) dbg[10] = (long long)clock64();
       if (kh == 0) {
-        // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
         int r_in = rt * 16 + j, col = 4 * g;
         const int n_out = m.n_out;
-        asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
+        asm volatile("" : "+v"(r_in), "+v"(col));
         const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
         float* og = out + row0 * n_out;
         const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + ot * 16 + col);
@@ -411,12 +424,11 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         }
       }
     }
-    if (dbg && tid == 0) dbg[11] = (long long)clock64();
-    park_queries();
-    lds_barrier();  // X, P and the parked queries change hands
-    RBL_NSTAMP();     // 8: output layer
-    dbg = nullptr;    // stamps describe the first group of each workgroup
+    if (m.out_tiles > 1) lds_barrier();  // X and P change hands
+    RBL_NSTAMP();  // 8: output layer
+    dbg = nullptr;  // stamps describe the first group of each workgroup
   }
+  if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
 #undef RBL_NSTAMP
 }
 
