@@ -51,8 +51,22 @@ def test_net2_vs_torch_cpu_golden():
 @pytest.mark.parametrize("d,f,hidden,layers_n,use_ln,rows", [
     (1, 6, 256, 2, True, 1472), (1, 6, 256, 2, True, 31), (1, 6, 256, 2, True, 33), (1, 4, 256, 2, True, 700),
     (2, 3, 256, 2, True, 513), (2, 6, 256, 2, True, 300), (1, 6, 256, 3, True, 257), (1, 6, 128, 2, True, 200),
-    (1, 6, 64, 1, False, 100), (1, 5, 256, 2, False, 129)])
+    (1, 6, 64, 1, False, 100), (1, 5, 256, 2, False, 129),
+    # more 64-row groups than CUs: the persistent (register-resident-weights) kernel loops, prefetching the next group
+    (1, 6, 256, 2, True, 40001), (2, 3, 256, 2, True, 33000), (2, 6, 256, 2, False, 20000)])
 def test_mlp_vs_float64_reference(d, f, hidden, layers_n, use_ln, rows):
+    _check_mlp(d, f, hidden, layers_n, use_ln, rows)
+
+
+@pytest.mark.parametrize("tile", [3, 4, 2, 0])
+def test_mlp_kernel_variants(tile, monkeypatch):
+    """The older kernel variants stay selectable (RBL_MLP_TILE) and are the fallback for shapes the resident kernel does
+    not take (n_layers != 2): same tolerance."""
+    monkeypatch.setenv("RBL_MLP_TILE", str(tile))
+    _check_mlp(1, 6, 256, 2, True, 5000)
+
+
+def _check_mlp(d, f, hidden, layers_n, use_ln, rows):
     e = _engine(d, f)
     rng = np.random.default_rng(hidden + rows)
     Q, H = e.Q, e.H
