@@ -14,8 +14,8 @@ independent lane sets (seeds rank*lanes+i), no data-path collective: "scaling": 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
                 measured live with HIP events on the engine streams (every 8th iteration of the timed region; the
-                two half-batches run on two streams, so a launch covers half the lanes and overlaps the other half's
-                CFR kernel)
+                two half-batches run on two streams, so a launch covers half the lanes and shares the GPU with the other
+                half's CFR kernel whenever that one finds free registers)
   roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration
   cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so, cpu_gen_threads = host cores) timed for a fixed
                 window on this box's host cores -- a reported baseline, not a target.
@@ -136,6 +136,9 @@ def main():
         cfr_t = st["cfr_ms"] / max(1, st["cfr_launches"]) * 1e-3
         net_tf = st["net_flops"] / max(1, st["net_launches"]) / net_t / 1e12 if net_t > 0 else 0.0
         cfr_gb = st["cfr_bytes"] / max(1, st["cfr_launches"]) / cfr_t / 1e9 if cfr_t > 0 else 0.0
+        H_, A_ = a.faces ** a.dice, 2 * a.dice * a.faces + 1
+        Q_ = 2 + A_ + 2 * H_
+        issued_ratio = 3.0 * (-(-Q_ // 32) * 32 * 256 + 256 * 256 + 256 * -(-H_ // 16) * 16) / (Q_ * 256 + 256 * 256 + 256 * H_)
         out = {
             "metric": "subgame CFR iters/sec (whole job), 1dx6f @1024 iters; self-play games/sec in games_per_s",
             "value": units_all / dt_max,
@@ -157,15 +160,16 @@ def main():
             "games_per_s": games_all / dt_max,
             "examples_per_s": n_examples * world / dt_max,
             # achieved = ALGORITHMIC flops 2*rows*(Q*256 + 256*256 + 256*H) per launch / mean launch time; the kernel issues
-            # 3 f16 MFMA products per multiply (+ tile padding), so the matrix pipe does ~3.2x this; what bounds the
-            # kernel is its f32 VALU epilogue (LayerNorm + erf-GELU on 512 activations per row), see DESIGN.md
-            "roofline": {"kernel": "mlp_fsplit_forward_kernel<1,8> (f16x2-split MFMA)", "bound": "mfma", "achieved": net_tf,
+            # 3 f16 MFMA products per multiply on padded tiles (K 27->32, H 6->16): 3.16x this on the matrix pipe.  On
+            # gfx950 the f16 MFMA pipe and f32 FMA-class VALU work do not overlap (scripts/micro/), and the LayerNorm +
+            # erf-GELU epilogue on 512 activations per row costs about as many issue cycles as the MFMAs: see DESIGN.md
+            "roofline": {"kernel": "mlp_resident_kernel<1,true> (f16x2-split MFMA, register-resident weights)", "bound": "mfma", "achieved": net_tf,
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
                          "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),
-                         "issued_mfma_tflops": net_tf * 3 * 1.0635,
+                         "issued_mfma_tflops": net_tf * issued_ratio,
                          "vs_f32_mfma_peak": net_tf / MFMA_F32_PEAK_TFLOPS},
-            "roofline_cfr": {"kernel": "cfr_step_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
+            "roofline_cfr": {"kernel": "cfr_rows_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
                              "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"]},
         }

@@ -45,7 +45,27 @@ template <int H, int A, int DICE, int FACES>
 __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
+  // children whose rows are requested together in the per-node passes.  2 and 4 were measured (MI355X, 1dx6f root): the
+  // step does not get shorter (the chain is the dependent fp64 adds, not the LDS reads) and 4 doubles the VGPR count
+  constexpr int kCh = 1;
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  // The lane's strategy and regrets are requested BEFORE its shape is known (their addresses only depend on the lane; the
+  // bound is the slab size, the real extent is applied at the LDS store): the shape look-up (lane -> shape id -> shape
+  // record -> tables) is a chain of dependent loads, and the state comes from Infinity Cache / HBM, not from L2.
+  constexpr int kB = H <= 6 ? 5 : 7;  // strides of blockDim = 128 that cover the depth-2 root tree (E * H = 540 / 810)
+  double s_[kB], r_[kB];
+  {
+    const size_t le = (size_t)lane * a.Emax * H;
+    const int cap = a.Emax * H;
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int i = tid + u * nthr;
+      if (i < cap) {
+        s_[u] = a.sigma[le + i];
+        r_[u] = a.regrets[le + i];
+      }
+    }
+  }
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
   const int N = sh.N, E = N - 1, L = sh.L, NI = sh.NI, nlev = sh.nlev;
   const int root_player = a.lane_root_player[lane], row_off = a.lane_row_off[lane];
@@ -71,6 +91,14 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   const double* bel = a.beliefs + (size_t)lane * 2 * H;
   double* rmean = a.root_mean + (size_t)lane * 2 * H;
 
+  long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
+  int dbg_k = 0;
+#define RBL_STAMP()                                                    \
+  do {                                                                 \
+    if (dbg && threadIdx.x == 0) dbg[dbg_k] = (long long)clock64();    \
+    ++dbg_k;                                                           \
+  } while (0)
+  RBL_STAMP();  // 0: start
   // ---------------------------------------------------------------- stage (flat, coalesced)
   {
     const int* gp = a.parent + sh.node_off;
@@ -82,24 +110,61 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     const int* gl = a.leaf_row + sh.node_off;
     const float* gv = a.values + (size_t)row_off * H;
     const int EH = E * H, LH = L * H;
-    const int n_all = max(max(EH, N), max(LH, FACES * H));
-    for (int i = tid; i < n_all; i += nthr) {
+    // every global load is issued before the first LDS store (a plain "load, store, next i" loop paid one memory round
+    // trip per stride: 5 for the root tree at 128 threads, a third of the whole step)
+    int tp = 0, ta = 0, tb = 0, te = 0, td = 0, ti = 0, tl = 0;
+    int8_t tm = 0;
+    if (tid < N) {
+      tp = gp[tid];
+      ta = ga[tid];
+      tb = gb[tid];
+      te = ge[tid];
+      td = gd[tid];
+      ti = gi[tid];
+      tl = gl[tid];
+    }
+    if (tid < FACES * H) tm = a.matches[tid];
+    float v_[kB];
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int i = tid + u * nthr;
+      if (i < LH) v_[u] = gv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < kB; ++u) {
+      const int i = tid + u * nthr;
+      if (i < EH) {
+        sig[i] = s_[u];
+        reg[i] = r_[u];
+      }
+      if (i < LH) lvals[i] = v_[u];
+    }
+    for (int i = tid + kB * nthr; i < max(EH, LH); i += nthr) {  // what the first kB strides did not cover
       if (i < EH) {
         sig[i] = g_sig[i];
         reg[i] = g_reg[i];
       }
       if (i < LH) lvals[i] = gv[i];
-      if (i < N) {
-        t_parent[i] = gp[i];
-        t_act[i] = ga[i];
-        t_cb[i] = gb[i];
-        t_ce[i] = ge[i];
-        t_depth[i] = gd[i];
-        t_irank[i] = gi[i];
-        t_lrow[i] = gl[i];
-      }
-      if (i < FACES * H) t_match[i] = a.matches[i];
     }
+    for (int i = tid; i < N; i += nthr) {  // N <= blockDim for every supported game except on the second lap
+      if (i != tid) {
+        tp = gp[i];
+        ta = ga[i];
+        tb = gb[i];
+        te = ge[i];
+        td = gd[i];
+        ti = gi[i];
+        tl = gl[i];
+      }
+      t_parent[i] = tp;
+      t_act[i] = ta;
+      t_cb[i] = tb;
+      t_ce[i] = te;
+      t_depth[i] = td;
+      t_irank[i] = ti;
+      t_lrow[i] = tl;
+    }
+    for (int i = tid; i < FACES * H; i += nthr) t_match[i] = i == tid ? tm : a.matches[i];
     if (tid < H) {
       rho0[tid] = bel[tid];
       rho1[tid] = bel[H + tid];
@@ -107,6 +172,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     __syncthreads();
   }
 
+  RBL_STAMP();  // 1: staged
   // value of a node without children, from its opponent-reach row (query_value_net :257-268 / terminal payoffs :80-98)
   auto leaf_value = [&](int n, const Row<H>& ro) {
     Row<H> out;
@@ -177,6 +243,9 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     __syncthreads();
   }
 
+  RBL_STAMP();  // 2: reach + leaf values
+  RBL_STAMP();  // 3
+  RBL_STAMP();  // 4
   // ---------------------------------------------------------------- bottom-up (update_regrets :542-574) fused with regret
   // matching (:619-634) and the regret discount (:639-650)
   double* rho_t = t == 0 ? rho0 : rho1;
@@ -190,16 +259,26 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       Row<H> x;
 #pragma unroll
       for (int h = 0; h < H; ++h) x.v[h] = 0.0;
-      for (int c = c0; c < c1; ++c) {
-        const Row<H> vc = load_row<H>(val + c * H);
-        if (mine) {
-          const Row<H> sc = load_row<H>(sig + (c - 1) * H);
+      // children in batches of kCh, accumulated in ascending order
+      for (int c = c0; c < c1; c += kCh) {
+        Row<H> vc[kCh], sc[kCh];
 #pragma unroll
-          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h] * sc.v[h];
-        } else {
+        for (int u = 0; u < kCh; ++u)
+          if (c + u < c1) {
+            vc[u] = load_row<H>(val + (c + u) * H);
+            if (mine) sc[u] = load_row<H>(sig + (c + u - 1) * H);
+          }
 #pragma unroll
-          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h];
-        }
+        for (int u = 0; u < kCh; ++u)
+          if (c + u < c1) {
+            if (mine) {
+#pragma unroll
+              for (int h = 0; h < H; ++h) x.v[h] += vc[u].v[h] * sc[u].v[h];
+            } else {
+#pragma unroll
+              for (int h = 0; h < H; ++h) x.v[h] += vc[u].v[h];
+            }
+          }
       }
       store_row<H>(val + n * H, x);
     }
@@ -227,10 +306,17 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       Row<H> s;
 #pragma unroll
       for (int h = 0; h < H; ++h) s.v[h] = 0.0;
-      for (int c = c0; c < c1; ++c) {
-        const Row<H> mc = load_row<H>(sig + (c - 1) * H);
+      for (int c = c0; c < c1; c += kCh) {
+        Row<H> mc[kCh];
 #pragma unroll
-        for (int h = 0; h < H; ++h) s.v[h] += mc.v[h];
+        for (int u = 0; u < kCh; ++u)
+          if (c + u < c1) mc[u] = load_row<H>(sig + (c + u - 1) * H);
+#pragma unroll
+        for (int u = 0; u < kCh; ++u)
+          if (c + u < c1) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) s.v[h] += mc[u].v[h];
+          }
       }
       store_row<H>(rho_t + t_irank[n] * H, s);
     }
@@ -245,6 +331,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     __syncthreads();
   }
 
+  RBL_STAMP();  // 5: bottom-up
   // ---------------------------------------------------------------- running mean of the root values (:579-590)
   if (tid < H) {
     double m = rmean[t * H + tid];
@@ -273,6 +360,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     __syncthreads();
   }
 
+  RBL_STAMP();  // 6: new reach
   // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
   {
     const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after;
@@ -300,6 +388,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     }
   }
 
+  RBL_STAMP();  // 7: write-back
   // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
   if (a.next_trav >= 0 && L > 0) {
     __syncthreads();  // val / reg are dead from here on: their bytes stage the query rows
@@ -344,6 +433,8 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     float* gq = a.queries + (size_t)row_off * Q;
     for (int i = tid; i < L * Q; i += nthr) gq[i] = qstage[i];
   }
+  RBL_STAMP();  // 8: queries
+#undef RBL_STAMP
 }
 
 }  // namespace

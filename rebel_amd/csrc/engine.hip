@@ -117,7 +117,7 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
     if ((size_t)s.L * g_.query_size() * 4 > stage) rows_ok_ = false;
   }
   if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
-  rows_block_ = env_int("RBL_CFR_ROWS_BLOCK", 128);
+  rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   if (env_int("RBL_CFR_DBG", 0)) {
     d_dbg_.alloc(L * 16);
     RBL_HIP_CHECK(hipMemset(d_dbg_.p, 0, L * 16 * sizeof(long long)));
