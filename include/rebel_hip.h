@@ -111,6 +111,11 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
  * the engine's params and net: out = dense full-tree strategy [N_full][H][A], N_full = rbl_unroll_tree(.., -1, 0, 1<<20).
  * The frontier is solved level by level, all subgames of a level as lanes of one launch sequence. */
 int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out);
+/* compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327; the core of recursive_eval.cc:116-160): as the
+ * to-leaf variant, but every subgame is stopped at its own iteration drawn from mt19937(seed) (weights i/2+1 on even i, in
+ * the reference's solver-construction order) and contributes its sampling strategy.  root_only != 0: subgames below the
+ * root are solved to the end of the game without the net (max_depth = 100000), on a helper engine of the same device. */
+int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, double* out);
 int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out); /* get_hand_values :694-696 */
 /* update_value_network (:672-676): writes the lane's two training examples, queries[2][Q], values[2][H] */
 int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values);

@@ -769,12 +769,22 @@ struct Recursive {
       per_node(c, nb);
     }
   }
-  void to_leaf(int node, const std::vector<double> b[2]) {  // :76-134, use_sampling_strategy = false
+  // sampled variant (:301-327): one draw per subgame, in the order the depth-first recursion builds the solvers
+  bool sampled = false, root_only = false;
+  std::mt19937 gen;
+  std::vector<double> iteration_weights;
+  void to_leaf(int node, const std::vector<double> b[2]) {  // :76-134
     const Node& nd = full[node];
     if (nd.last_bid == g.liar) return;
-    Solver* s = build(g, nd.last_bid, nd.player, b[0].data(), b[1].data(), sp, net, true);
+    orc_params p = sp;
+    if (sampled) {
+      std::discrete_distribution<int> dist(iteration_weights.begin(), iteration_weights.end());
+      p.num_iters = dist(gen);
+      if (root_only && node != 0) p.max_depth = 100000;
+    }
+    Solver* s = build(g, nd.last_bid, nd.player, b[0].data(), b[1].data(), p, net, true);
     s->multistep();
-    const std::vector<double> strat = s->average();
+    const std::vector<double> strat = sampled ? s->sampling() : s->average();
     const std::vector<Node> part = s->trav().tree;
     delete s;
     struct Item {
@@ -819,6 +829,22 @@ void orc_strategy_recursive(int dice, int faces, const orc_params* params, int t
     r.to_leaf(0, b);
   else
     r.per_node(0, b);
+}
+
+void orc_strategy_recursive_sampled(int dice, int faces, const orc_params* params, int seed, int root_only, int net_mode,
+                                    orc_net_fn net_fn, void* net_user, const char* torchscript_path, double* out) {
+  (void)torchscript_path;
+  Rules g(dice, faces);
+  Recursive r(g, *params, make_net(net_mode, net_fn, net_user, nullptr, nullptr), out);
+  std::fill(out, out + r.full.size() * (size_t)g.H * g.A, 0.0);
+  r.sampled = true;
+  r.root_only = root_only != 0;
+  r.gen.seed(seed);
+  for (int i = 0; i < params->num_iters; ++i) r.iteration_weights.push_back(i % 2 ? 0.0 : (i / 2. + 1));  // :306-310
+  std::vector<double> b[2];
+  b[0].assign(g.H, 1. / g.H);
+  b[1].assign(g.H, 1. / g.H);
+  r.to_leaf(0, b);
 }
 
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]) {

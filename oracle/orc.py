@@ -97,6 +97,9 @@ class Oracle:
         L.orc_strategy_recursive.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, NET_FN, C.c_void_p,
                                              C.c_char_p, C.POINTER(C.c_double)]
         L.orc_strategy_recursive.restype = None
+        L.orc_strategy_recursive_sampled.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, NET_FN,
+                                                     C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        L.orc_strategy_recursive_sampled.restype = None
         L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                                         C.c_int]
         L.orc_synthetic_net.restype = None
@@ -165,6 +168,17 @@ class Oracle:
         cb = _wrap_net(net_fn, H) if net_fn is not None else NET_FN()
         self.lib.orc_strategy_recursive(d, f, C.byref(params), int(to_leaf), net, cb, None,
                                         (torchscript_path or "").encode(), _dp(out))
+        return out
+
+    def strategy_recursive_sampled(self, d, f, params, seed, root_only=False, net=NET_ZERO, net_fn=None,
+                                   torchscript_path=None):
+        """compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327) -> dense [N_full][H][A]."""
+        H, A = self.num_hands(d, f), self.num_actions(d, f)
+        n = len(self.unroll_tree(d, f, -1, 0, 1000000))
+        out = np.zeros((n, H, A))
+        cb = _wrap_net(net_fn, H) if net_fn is not None else NET_FN()
+        self.lib.orc_strategy_recursive_sampled(d, f, C.byref(params), int(seed), int(root_only), net, cb, None,
+                                                (torchscript_path or "").encode(), _dp(out))
         return out
 
     def exploitability2(self, d, f, strategy):

@@ -70,6 +70,12 @@ void orc_rl_run(int dice, int faces, double random_action_prob, int sample_leaf,
 void orc_strategy_recursive(int dice, int faces, const orc_params* params, int to_leaf, int net_mode, orc_net_fn net_fn,
                             void* net_user, const char* torchscript_path, double* out);
 
+/* ---- compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327): every subgame is stopped at its own
+ *      iteration, drawn from mt19937(seed) with weights (i even ? i/2+1 : 0), and contributes its SAMPLING strategy;
+ *      root_only: subgames below the root are solved to the end of the game (max_depth = 100000) ---- */
+void orc_strategy_recursive_sampled(int dice, int faces, const orc_params* params, int seed, int root_only, int net_mode,
+                                    orc_net_fn net_fn, void* net_user, const char* torchscript_path, double* out);
+
 /* ---- full-tree evaluation (subgame_solving.cc:802-816): strategy dense [N_full][H][A] ---- */
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]);
 

@@ -260,6 +260,17 @@ void orc_strategy_recursive(int dice, int faces, const orc_params* params, int t
       for (int a = 0; a < A; ++a) out[(n * H + h) * A + a] = s[n].empty() ? 0.0 : s[n][h][a];
 }
 
+void orc_strategy_recursive_sampled(int dice, int faces, const orc_params* params, int seed, int root_only, int net_mode,
+                                    orc_net_fn net_fn, void* net_user, const char* torchscript_path, double* out) {
+  Game game(dice, faces);
+  auto net = make_net(game, net_mode, net_fn, net_user, torchscript_path, nullptr, nullptr);
+  const TreeStrategy s = compute_sampled_strategy_recursive_to_leaf(game, to_params(params), net, seed, root_only != 0);
+  const int H = game.num_hands(), A = game.num_actions();
+  for (size_t n = 0; n < s.size(); ++n)
+    for (int h = 0; h < H; ++h)
+      for (int a = 0; a < A; ++a) out[(n * H + h) * A + a] = s[n].empty() ? 0.0 : s[n][h][a];
+}
+
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]) {
   Game game(dice, faces);
   const auto tree = unroll_tree(game);

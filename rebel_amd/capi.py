@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_strategy_recursive", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_engine_timing", "rbl_engine_stats",
 ]
@@ -111,6 +111,7 @@ def lib():
         "rbl_solver_best_response": (C.c_int, [vp, C.c_int, dp]),
         "rbl_exploitability2": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "rbl_strategy_recursive": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_strategy_recursive_sampled": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_hand_values": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_examples": (C.c_int, [vp, C.c_int, fp, fp]),
         "rbl_solver_get_queries": (C.c_int, [vp, fp]),
@@ -296,6 +297,13 @@ class Engine:
         n = len(unroll_tree(self.dice, self.faces, -1, 0, 1000000))
         out = np.zeros((n, self.H, self.A))
         _check(self.L.rbl_strategy_recursive(self.h, int(to_leaf), _p(out, C.c_double)))
+        return out
+
+    def strategy_recursive_sampled(self, seed, root_only=False):
+        """compute_sampled_strategy_recursive_to_leaf(seed, root_only) with this engine's params and net."""
+        n = len(unroll_tree(self.dice, self.faces, -1, 0, 1000000))
+        out = np.zeros((n, self.H, self.A))
+        _check(self.L.rbl_strategy_recursive_sampled(self.h, int(seed), int(root_only), _p(out, C.c_double)))
         return out
 
     def hand_values(self, lane, player):

@@ -95,6 +95,7 @@ class Engine {
   void stats(rbl_kernel_stats* out, bool reset);
 
   const Rules& rules() const { return g_; }
+  int device() const { return device_; }
   const rbl_params& params() const { return p_; }
   const ShapeTables& tables() const { return tabs_; }
   hipStream_t stream() const { return stream_; }

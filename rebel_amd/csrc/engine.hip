@@ -8,6 +8,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <random>
 
 namespace rbl {
 
@@ -814,6 +817,115 @@ void strategy_recursive(Engine& e, bool to_leaf, double* out) {
   }
 }
 
+// compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327): like the to-leaf recursion above, but every
+// subgame is stopped at its own iteration -- one draw from mt19937(seed) per subgame, weights (i even ? i/2+1 : 0), in the
+// order in which the reference's depth-first recursion builds its solvers -- and contributes its SAMPLING strategy
+// (last_strategies at that iteration; it also propagates the beliefs).  The draw order only depends on the tree, so all
+// draws are made up front; then the frontier is solved level by level with one lane per subgame, each lane snapshotting
+// its strategy at its own act_iteration.  root_only: subgames below the root are solved to the end of the game
+// (max_depth = 100000, no value net) on a helper engine.
+void strategy_recursive_sampled(Engine& e, int seed, bool root_only, double* out) {
+  const Rules& g = e.rules();
+  const int H = g.H, A = g.A;
+  const std::vector<Node> full = unroll_tree(g, -1, 0, 1000000);
+  std::fill(out, out + full.size() * (size_t)H * A, 0.0);
+  std::unique_ptr<Engine> deep;  // root_only: full-depth subgames
+  if (root_only) {
+    rbl_params dp = e.params();
+    dp.max_depth = 100000;
+    deep.reset(new Engine(e.device(), g.dice, g.faces, dp, e.max_lanes()));
+    deep->set_net_zero();
+  }
+  auto engine_of = [&](int node) -> Engine& { return root_only && node != 0 ? *deep : e; };
+
+  // ---- 1. act_iteration of every subgame root, in the reference's solver-construction order
+  std::vector<int> act(full.size(), -1);
+  {
+    std::mt19937 gen(seed);
+    std::vector<double> w;
+    for (int i = 0; i < e.params().num_iters; ++i) w.push_back(i % 2 ? 0.0 : (i / 2. + 1));
+    std::function<void(int)> visit = [&](int node) {
+      if (full[node].last_bid == g.liar) return;
+      std::discrete_distribution<int> dist(w.begin(), w.end());
+      act[node] = dist(gen);
+      const ShapeTables& tb = engine_of(node).tables();
+      const ShapeDev& sh = tb.shapes[full[node].last_bid + 1];
+      std::vector<std::pair<int, int>> queue{{node, 0}};  // (full node, partial node), BFS
+      for (size_t qi = 0; qi < queue.size(); ++qi) {
+        const int f = queue[qi].first, p = queue[qi].second;
+        const int pc0 = tb.cb[sh.node_off + p], pc1 = tb.ce[sh.node_off + p];
+        for (int k = 0; k < pc1 - pc0; ++k) queue.push_back({full[f].cb + k, pc0 + k});
+        if (pc0 == pc1 && full[f].cb != full[f].ce) visit(f);
+      }
+    };
+    visit(0);
+  }
+
+  // ---- 2. level by level
+  struct Item {
+    int node;
+    std::vector<double> b;  // [2][H]
+  };
+  std::vector<Item> frontier;
+  frontier.push_back(Item{0, std::vector<double>(2 * (size_t)H, 1.0 / H)});
+  std::vector<double> dense;
+  while (!frontier.empty()) {
+    std::vector<Item> next;
+    Engine& en = engine_of(frontier[0].node);  // a level is either the root alone or entirely below it
+    const ShapeTables& tb = en.tables();
+    for (size_t base = 0; base < frontier.size(); base += en.max_lanes()) {
+      const int B = (int)std::min<size_t>(en.max_lanes(), frontier.size() - base);
+      std::vector<int32_t> bid(B), pl(B), ai(B);
+      std::vector<double> bel((size_t)B * 2 * H);
+      int steps = 0;
+      for (int i = 0; i < B; ++i) {
+        const Item& it = frontier[base + i];
+        bid[i] = full[it.node].last_bid;
+        pl[i] = full[it.node].player;
+        ai[i] = act[it.node];
+        steps = std::max(steps, ai[i]);
+        std::copy(it.b.begin(), it.b.end(), bel.begin() + (size_t)i * 2 * H);
+      }
+      en.reset(B, bid.data(), pl.data(), bel.data(), ai.data());
+      en.multistep(steps);
+      for (int i = 0; i < B; ++i) {
+        const Item& it = frontier[base + i];
+        const ShapeDev& sh = tb.shapes[bid[i] + 1];
+        dense.resize((size_t)sh.N * H * A);
+        en.get_snapshot(i, dense.data());
+        struct Q {
+          int f, p;
+          std::vector<double> r;
+        };
+        std::vector<Q> queue;
+        queue.push_back(Q{it.node, 0, it.b});
+        for (size_t qi = 0; qi < queue.size(); ++qi) {
+          Q cur = queue[qi];
+          std::copy(dense.begin() + (size_t)cur.p * H * A, dense.begin() + (size_t)(cur.p + 1) * H * A,
+                    out + (size_t)cur.f * H * A);
+          const Node& fn = full[cur.f];
+          const int pc0 = tb.cb[sh.node_off + cur.p], pc1 = tb.ce[sh.node_off + cur.p];
+          int lo, hi;
+          g.bid_range(fn.last_bid, &lo, &hi);
+          for (int k = 0; k < pc1 - pc0; ++k) {
+            Q ch{fn.cb + k, pc0 + k, cur.r};
+            double* r = ch.r.data() + (size_t)fn.player * H;
+            for (int h = 0; h < H; ++h) r[h] *= dense[((size_t)cur.p * H + h) * A + lo + k];
+            queue.push_back(std::move(ch));
+          }
+          if (pc0 == pc1 && fn.cb != fn.ce) {
+            Item nr{cur.f, cur.r};
+            normalize_safe(nr.b.data(), H, kEps, nr.b.data());
+            normalize_safe(nr.b.data() + H, H, kEps, nr.b.data() + H);
+            next.push_back(std::move(nr));
+          }
+        }
+      }
+    }
+    frontier.swap(next);
+  }
+}
+
 // =================================================================================================== SelfPlay
 SelfPlay::SelfPlay(Engine* e, int n_lanes, const int32_t* seeds, double random_action_prob, bool sample_leaf)
     : e_(e), n_(n_lanes), rap_((float)random_action_prob), leaf_(sample_leaf) {
@@ -1079,6 +1191,10 @@ int rbl_solver_best_response(rbl_engine* e, int traverser, double* out) {
 }
 int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out) {
   return guard([&] { rbl::strategy_recursive(e->impl, to_leaf != 0, out); });
+}
+
+int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, double* out) {
+  return guard([&] { rbl::strategy_recursive_sampled(e->impl, seed, root_only != 0, out); });
 }
 int rbl_exploitability2(int device, int dice, int faces, const double* strategy, double out[2]) {
   return guard([&] {  // compute_exploitability2 (subgame_solving.cc:802-816): two full-tree BR sweeps, uniform beliefs

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""GPU counterpart of the reference's `recursive_eval` tool (csrc/liars_dice/recursive_eval.cc:193-426), on the C ABI.
+
+    python scripts/recursive_eval.py --num_dice 1 --num_faces 4 --subgame_iters 1024 --mdp_depth 2 --num_repeats 64 \
+        --net zero|<Net2 state dict .pt/.npz> [--cfr] [--no_linear] [--root_only] [--seed0 0]
+
+What it reproduces:
+  * "Solving the game for the full tree": the full-tree solver with exploitability printed at iterations 2^k and at the
+    end (recursive_eval.cc:269-296);
+  * "Recursive solving": `num_repeats` sampled strategies (compute_sampled_strategy_recursive_to_leaf, seeds 0..R-1,
+    recursive_solving.cc:301-327 -- on the GPU every subgame of a tree level is a lane, rbl_strategy_recursive_sampled),
+    averaged with the reach of the acting player as weights (recursive_eval.cc:136-160, 336-363; float32 like the
+    reference's tensors), exploitability at 2^k repeats and at the end;
+  * the machine-readable line `XXX {"net":..., "full_tree":..., "repeated toleaf N":...}` that scripts/eval_all.py:100-104
+    greps for.
+Not reproduced: the EV-against-full-strategy (`YYY`) line, regret reports, strategy dumps, oracle-net mode.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def reach_of_actor(tree, strategy, H):
+    """stats.reach_probabilities[player(node)][node] (stats.cc / subgame_solving.cc:54-78): own-action reach of the
+    player acting at the node, from uniform initial beliefs.  tree rows (rbl_unroll_tree): (last_bid, player, children_begin,
+    children_end, parent, depth)."""
+    N = len(tree)
+    reach = np.zeros((2, N, H))
+    reach[:, 0, :] = 1.0 / H
+    for n in range(N):
+        _, player, cb, ce, _, _ = tree[n]
+        if cb == ce:
+            continue
+        lo = tree[cb][0]  # first legal action = last_bid of the first child
+        for c in range(cb, ce):
+            a = lo + (c - cb)
+            for p in (0, 1):
+                reach[p, c] = reach[p, n] * strategy[n, :, a] if p == player else reach[p, n]
+    players = tree[:, 1]
+    return reach[players, np.arange(N)]  # [N][H]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--num_dice", type=int, default=1)
+    ap.add_argument("--num_faces", type=int, default=4)
+    ap.add_argument("--subgame_iters", type=int, default=1024)
+    ap.add_argument("--mdp_depth", type=int, default=-1)
+    ap.add_argument("--num_repeats", type=int, default=-1)
+    ap.add_argument("--net", default="")
+    ap.add_argument("--root_only", action="store_true")
+    ap.add_argument("--no_linear", action="store_true")
+    ap.add_argument("--optimistic", action="store_true")
+    ap.add_argument("--cfr", action="store_true")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--max_lanes", type=int, default=4096)
+    a = ap.parse_args()
+
+    from rebel_amd import capi
+
+    d, f = a.num_dice, a.num_faces
+    base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear, use_cfr=a.cfr, optimistic=a.optimistic)
+    tree = capi.unroll_tree(d, f, -1, 0, 1000000)
+    print(f"num_dice={d} num_faces={f}")
+    print(f"Tree of depth {int(tree[:, 5].max())} has {len(tree)} nodes")
+    print("##############################################\n##### Solving the game for the full tree #####\n"
+          "##############################################")
+    full = capi.Engine(d, f, capi.make_params(max_depth=100000, **base), max_lanes=1, device=a.device)
+    full.set_net_zero()
+    H = full.H
+    full.reset([-1], [0], np.full((1, 2, H), 1.0 / H))
+    for it in range(a.subgame_iters):
+        full.step(it % 2)
+        if ((it + 1) & it) == 0 or it + 1 == a.subgame_iters:
+            ex = capi.exploitability2(d, f, full.get(0, capi.GET_AVERAGE), a.device)
+            print("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e" % (it + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2))
+    full_strategy = full.get(0, capi.GET_AVERAGE)
+    ex = capi.exploitability2(d, f, full_strategy, a.device)
+    print(f"Full FP exploitability: {(ex[0] + ex[1]) / 2:.6f} ({ex[0]:.6f},{ex[1]:.6f})")
+    results = [("net", a.net), ("full_tree", "%.6f" % ((ex[0] + ex[1]) / 2))]
+
+    if a.net:
+        assert a.mdp_depth > 0, "--mdp_depth is required with --net"
+        print("##############################################\n##### Recursive solving                      #\n"
+              "##############################################")
+        eng = capi.Engine(d, f, capi.make_params(max_depth=a.mdp_depth, **base), max_lanes=a.max_lanes, device=a.device)
+        if a.net == "zero":
+            eng.set_net_zero()
+        else:
+            from rebel_amd.models import mlp_weights_from_state_dict
+            if a.net.endswith(".npz"):
+                sd = dict(np.load(a.net))
+            else:
+                import torch
+                sd = torch.load(a.net, map_location="cpu")
+            eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
+        summed = reach_sum = None
+        for sid in range(max(a.num_repeats, 0)):
+            s = eng.strategy_recursive_sampled(sid, a.root_only).astype(np.float32)
+            w = reach_of_actor(tree, s.astype(np.float64), H).astype(np.float32)[:, :, None]
+            summed = s * w if summed is None else summed + s * w
+            reach_sum = w if reach_sum is None else reach_sum + w
+            if ((sid + 1) & sid) == 0 or sid + 1 == a.num_repeats:
+                final = (summed / (reach_sum + np.float32(1e-6))).astype(np.float64)
+                ex = capi.exploitability2(d, f, final, a.device)
+                print("%5d: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1]))
+                results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
+    for name, val in results[1:]:
+        print(f" {name} {val}")
+    print("XXX " + json.dumps(dict(results), separators=(", ", ":")))
+
+
+if __name__ == "__main__":
+    main()

@@ -69,3 +69,43 @@ def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port):
     want = port.strategy_recursive(d, f, orc.make_params(**kw), to_leaf=to_leaf, net=orc.NET_SYNTHETIC)
     assert got.shape == want.shape and np.array_equal(got, want)
     assert np.array_equal(capi.exploitability2(d, f, got), port.exploitability2(d, f, want))
+
+
+@pytest.mark.parametrize("d,f,depth,iters,seed,root_only,use_cfr", [
+    (1, 4, 2, 32, 0, False, True), (1, 4, 2, 33, 5, False, True), (1, 5, 2, 16, 1, False, True), (1, 4, 1, 12, 2, True, True),
+    (1, 4, 2, 24, 3, True, True), (2, 2, 2, 20, 4, False, True), (1, 4, 2, 16, 6, False, False)])
+def test_sampled_recursive_strategy_bit_exact(d, f, depth, iters, seed, root_only, use_cfr, port):
+    """compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327, the core of recursive_eval): per-subgame
+    act iterations drawn up front in the reference's order, level-batched lanes snapshotting at their own iteration."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=iters, max_depth=depth, linear_update=True, use_cfr=use_cfr)
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=48)
+    e.set_net_synthetic()
+    got = e.strategy_recursive_sampled(seed, root_only)
+    want = port.strategy_recursive_sampled(d, f, orc.make_params(**kw), seed, root_only, net=orc.NET_SYNTHETIC)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # a different seed stops the subgames elsewhere
+    assert not np.array_equal(got, e.strategy_recursive_sampled(seed + 1, root_only))
+
+
+def test_recursive_eval_tool(tmp_path):
+    """scripts/recursive_eval.py (the reference's recursive_eval CLI on the C ABI): runs, prints the XXX json line the
+    reference's eval_all.py parses; with a subgame depth that covers the whole game the sampled strategies are last
+    strategies of the full-tree solver at random even iterations, and their reach-weighted average must beat a single one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py"), "--num_dice", "1", "--num_faces",
+                        "4", "--subgame_iters", "64", "--mdp_depth", "100", "--num_repeats", "8", "--net", "zero", "--cfr"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("XXX ")][-1]
+    d = json.loads(line[4:])
+    assert d["net"] == "zero" and float(d["full_tree"]) < 0.05
+    assert float(d["repeated toleaf 8"]) < float(d["repeated toleaf 1"])
+    assert "Iter=      64" in r.stdout

@@ -94,3 +94,17 @@ def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port, ref):
     o = port.strategy_recursive(d, f, p, to_leaf=to_leaf, net=orc.NET_SYNTHETIC)
     assert a.shape == o.shape and np.array_equal(a, o)
     assert np.array_equal(ref.exploitability2(d, f, a), port.exploitability2(d, f, o))
+
+
+@pytest.mark.parametrize("d,f,depth,iters,seed,root_only", [(1, 4, 2, 16, 0, False), (1, 4, 2, 33, 7, False),
+                                                            (1, 4, 1, 16, 3, True), (1, 5, 2, 24, 1, False)])
+def test_sampled_recursive_strategy_port_vs_reference(d, f, depth, iters, seed, root_only, ref, port):
+    """compute_sampled_strategy_recursive_to_leaf (recursive_solving.cc:301-327): the port's restatement (draw order,
+    per-subgame num_iters, sampling strategy for output and belief propagation, root_only depth) vs the reference."""
+    from oracle import orc
+
+    p = orc.make_params(num_iters=iters, max_depth=depth, linear_update=True, use_cfr=True)
+    net = orc.NET_ZERO if root_only else orc.NET_SYNTHETIC
+    a = ref.strategy_recursive_sampled(d, f, p, seed, root_only, net=net)
+    o = port.strategy_recursive_sampled(d, f, p, seed, root_only, net=net)
+    assert np.array_equal(a, o)
