@@ -120,6 +120,7 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
     if ((size_t)s.L * g_.query_size() * 4 > stage) rows_ok_ = false;
   }
   if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
+  rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   if (env_int("RBL_CFR_DBG", 0)) {
     d_dbg_.alloc(L * 16);
@@ -359,7 +360,11 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
     part_lane_[pt] = (int)((int64_t)B * pt / n_parts_);
     part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
   }
-  for (int pt = 0; pt < 4; ++pt) part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
+  for (int pt = 0; pt < 4; ++pt) {
+    part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
+    part_rows_lds_[pt] = 0;
+    part_rows_block_[pt] = 64;
+  }
   for (int b = 0; b < B; ++b) {
     const ShapeDev& s = tabs_.shapes[h_shape_[b]];
     int e_par[2] = {0, 0};
@@ -369,6 +374,17 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
     for (int t = 0; t < 2; ++t) {
       const int et = e_par[(h_player_[b] == t) ? 0 : 1];
       part_bytes_[part][t] += 8.0 * H * ((s.N - 1) + 5.0 * et) + 4.0 * s.L * (Q + H);
+    }
+    // the row kernel's launch shape follows the largest tree of the part: LDS request (= lanes per CU) and 64 threads when
+    // every tree has at most 64 rows.  Uniformly small batches (deep levels of recursive solving, late-game lanes) run
+    // 25-30 % faster; a part that holds a root subgame keeps the full shape.  (Sorting the lanes by tree size so that one
+    // part gets the small trees was tried: no gain, the kernel is instruction-issue-bound at 8 lanes per CU.)
+    if (rows_fit_) {
+      part_rows_lds_[part] = std::max(part_rows_lds_[part], cfr_rows_lds_bytes(s.N, s.NI, g_.H, s.L, g_.faces));
+      if (s.N > 64) part_rows_block_[part] = rows_block_;
+    } else {
+      part_rows_lds_[part] = rows_lds_bytes_;
+      part_rows_block_[part] = rows_block_;
     }
   }
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
@@ -432,7 +448,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     hipStream_t st = part_stream(part);
     a.lane0 = l0;
     time_begin(0, st);
-    if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, rows_block_, rows_lds_bytes_, st)))
+    if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
       launch_cfr(a, cnt, block_, lds_bytes_, st);
     time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());

@@ -1,0 +1,14 @@
+"""Self-play epochs with the elementwise synthetic net: the value net costs next to nothing, so the wall time per iteration is the
+CFR step kernel's share on the self-play mix of subgame sizes (RBL_PARTS / RBL_CFR_ROWS* env vars apply)."""
+import sys, time, numpy as np
+sys.path.insert(0, '.')
+from rebel_amd import capi
+from rebel_amd.sharding import lane_seeds
+B, iters = 4096, 1024
+e = capi.Engine(1, 6, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
+e.set_net_synthetic()
+sp = capi.SelfPlay(e, lane_seeds(0, B), random_action_prob=0.25, sample_leaf=True)
+sp.advance(collect=False); e.sync()
+for ep in range(4):
+    t = time.time(); n, *_ = sp.advance(collect=True); e.sync(); dt = time.time() - t
+    print(f"epoch {ep}: {dt / iters * 1e6:.1f} us per iteration, rows/iteration {e.total_rows()}, mean N {np.mean([e.tree_size(i) for i in range(B)]):.1f}")
