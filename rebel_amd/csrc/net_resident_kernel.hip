@@ -10,19 +10,25 @@
 //     what counts is that each phase runs at its own pipe's rate and that the VALU phase is short;
 //   * v_mfma_f32_16x16x32_f16 honours f16 subnormals, so the low halves of the f16x2 split need no 2^11 pre-scale and
 //     all three partial products can go into ONE f32 accumulator.
-// Hence: a PERSISTENT workgroup per CU (8 waves, 2 per SIMD, 256-VGPR budget).  Wave w owns output features
-// [32w, 32w+32) of both dense layers and keeps its slice of the weights -- layer 0 (16 VGPRs) and the 256x256 hidden layer
-// (128 VGPRs, hi + lo halves) -- in registers for the whole launch, looping over 64-row groups.  Weight traffic drops from
-// once per group to once per workgroup (16x fewer bytes at 270k rows).  The next group's query rows are fetched into
-// registers while the current group computes.  Activations are exchanged through LDS exactly as in the tile-3 kernel
-// (row-major f32 image of the pre-activations, rewritten in place as f16x2 MFMA B fragments).
+// Hence: a PERSISTENT workgroup per CU (8 waves, 2 per SIMD, 256-VGPR budget), looping over 64-row groups.  Wave w owns
+// output features [32w, 32w+32) of both dense layers and keeps its slice of the 256x256 hidden layer (hi + lo halves,
+// 128 VGPRs) in registers for the whole launch: weight traffic drops from once per group to once per workgroup (16x fewer
+// bytes at 270k rows; SQ_INSTS_VMEM 3.67 M -> 0.48 M per launch).  Layer-0 weights (4 KB per wave) are re-read from L2
+// once per group, requested as soon as registers are free; the next group's query rows are fetched in B-fragment order
+// while the current group computes.
 //
-// VALU diet (the epilogue is ~55 % of the remaining time): GELU is evaluated on z = x / sqrt2 and returns GELU(x) / sqrt2
-// = max(z, 0) - t erfc(t) / 2 with t = min(|z|, 4) and erfc(t) / 2 = 2^(t R(t) - 1) (R as in net_kernels.hip); the
-// 1 / sqrt2 going in is folded into the LayerNorm scale and shift (host: ln_b / sqrt2), the sqrt2 coming out into the
-// next layer's weights (host: W * sqrt2).  15 VALU instructions per element pair instead of 19; LayerNorm keeps the
-// centred values from the variance pass (5 instead of 6); the split needs no rescale (5 instead of 6); one accumulator
-// means one fma per pair to form the pre-activation (1 instead of 2).
+// Epilogue ON THE ACCUMULATORS.  The MFMA's D layout (lane (j, g): features 4g..4g+3 of each of the wave's two tiles,
+// row j) is exactly one 16-byte B fragment of k-step `w` of the next layer, provided that layer's weights are packed
+// with k running as (tile, g, r) inside a k-step (pack_mlp, tile 5).  So bias, LayerNorm and GELU are applied in
+// registers and the result goes straight into the next layer's operand image: no f32 image, no transposition through LDS;
+// per layer the waves exchange one float per row and wave (variance partials) and 2 LDS-only barriers.  The output
+// layer's first tile is multiplied from registers too (each wave its own k slice; partials summed by four waves).
+//
+// VALU diet (the epilogue is about half of the time): per element pair, LayerNorm 3 (weights and biases are centred over
+// the output features on the host, so only the variance is computed) + GELU 13 (gelu_z below; the 1/sqrt2 going in is
+// folded into the LayerNorm scale and shift, the -sqrt2 coming out into the next layer's weights) + split 4 + bias 1 = 21
+// instructions, against 37 in the tile-3 kernel.  Measured (MI355X, 270k rows): 18.8 k cycles per 64-row group and CU
+// (tile 3: 24.7 k), ~145 us per launch alone; PMC: MFMA busy 33 % + VALU busy 45 % of the time, never together.
 //
 // Supported shape: n_layers == 2 (one hidden layer, the reference's configuration liars_sp.yaml:28-33), n_hidden == 256,
 // n_in <= 128, n_out <= 64.  Anything else stays on the tile-3 kernel.
