@@ -113,9 +113,13 @@ __device__ __forceinline__ void lds_barrier() {
 // hipcc on its own emits "4 ds_reads, wait, 12 MFMAs" with nothing in flight across the wait; the sched_barriers pin a
 // 3-slot ring instead: the fragments of step s+2 are requested before the MFMAs of step s issue, so every LDS round trip
 // has ~200 cycles of matrix work in front of it.
-template <int NKS>
-__device__ __forceinline__ void gemm_resident(const Frag (&wh)[NKS][kOTW], const Frag (&wl)[NKS][kOTW],
+// NRES k-steps with weights in wh / wl, then NTAIL more from th / tl (fragments requested from L2 just before the call:
+// they land while the resident k-steps are being multiplied); NT1 = max(NTAIL, 1) is only the array bound
+template <int NRES, int NTAIL, int NT1>
+__device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW],
+                                              const Frag (&th)[NT1][kOTW], const Frag (&tl)[NT1][kOTW],
                                               const f32x4* __restrict__ X, int lane, f32x4 (&acc)[kOTW][kRT]) {
+  constexpr int NKS = NRES + NTAIL;
   constexpr int NS = NKS * kRT, PF = 2;
   Frag xb[PF + 1][2];
 #pragma unroll
@@ -132,12 +136,17 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NKS][kOTW], const
       xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
+    const bool tail = ks >= NRES;
+    const int kr = tail ? 0 : ks, kt = tail ? ks - NRES : 0;
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wl[ks][ot].h, xb[slot][0].h, acc[ot][rt]);
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(tail ? tl[kt][ot].h : wl[kr][ot].h, xb[slot][0].h, acc[ot][rt]);
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wh[ks][ot].h, xb[slot][1].h, acc[ot][rt]);
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(tail ? th[kt][ot].h : wh[kr][ot].h, xb[slot][1].h, acc[ot][rt]);
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) acc[ot][rt] = RBL_MFMA(wh[ks][ot].h, xb[slot][0].h, acc[ot][rt]);
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(tail ? th[kt][ot].h : wh[kr][ot].h, xb[slot][0].h, acc[ot][rt]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -169,11 +178,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
   // ---------------------------------------------------------------- this wave's weights, resident for the whole launch
   const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
-  Frag w1h[kKS][kOTW], w1l[kKS][kOTW];
+  // With more than one input k chunk (n_in > 32: 2dx3f, 2dx6f) the per-group state no longer fits next to all 8 hidden
+  // k-steps (hipcc spilled 4-6 weight fragments and reloaded them from scratch every group); the last kTail k-steps are
+  // then streamed from L2 per group instead, requested right before the hidden GEMM and used at its end.
+  constexpr int kTail = K0C == 1 ? 0 : (K0C == 2 ? 1 : (K0C == 3 ? 3 : 4)), kRes = kKS - kTail, kT1 = kTail > 0 ? kTail : 1;
+  Frag w1h[kRes][kOTW], w1l[kRes][kOTW];
+  const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
   {
-    const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
 #pragma unroll
-    for (int ks = 0; ks < kKS; ++ks)
+    for (int ks = 0; ks < kRes; ++ks)
 #pragma unroll
       for (int ot = 0; ot < kOTW; ++ot) {
         w1h[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
@@ -359,7 +372,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
     // -------------------------------------------------------------- layer 0
     zero_acc();
-    gemm_resident<K0C>(th, tl, X, lane, acc);
+    gemm_resident<K0C, 0, K0C>(th, tl, th, tl, X, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     RBL_NSTAMP();  // 3
     epilogue_regs(std::false_type{}, m.inv_scale[0], prm);
@@ -367,7 +380,21 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
     // -------------------------------------------------------------- hidden layer, weights from registers
     zero_acc();
-    gemm_resident<kKS>(w1h, w1l, X, lane, acc);
+    {
+      Frag t7h[kT1][kOTW], t7l[kT1][kOTW];
+      if constexpr (kTail > 0) {
+        const f32x4* wt = w1 + (size_t)kRes * kOTW * 2 * 64;
+        asm volatile("" : "+s"(wt));  // a fresh load every group
+#pragma unroll
+        for (int ks = 0; ks < kTail; ++ks)
+#pragma unroll
+          for (int ot = 0; ot < kOTW; ++ot) {
+            t7h[ks][ot].v = wt[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+            t7l[ks][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+          }
+      }
+      gemm_resident<kRes, kTail, kT1>(w1h, w1l, t7h, t7l, X, lane, acc);
+    }
     RBL_NSTAMP();  // 5: hidden gemm
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
