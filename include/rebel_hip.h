@@ -107,6 +107,12 @@ int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out); /* sigma_last
 int rbl_solver_set_strategy(rbl_engine* e, int lane, const double* strategy);
 int rbl_solver_best_response(rbl_engine* e, int traverser, double* out);
 int rbl_exploitability2(int device, int dice, int faces, const double* strategy, double out[2]);
+/* compute_ev (subgame_solving.cc:931-973) per lane: root values [B][H] of the traverser following the lane's sigma (the
+ * opponent's reach under the same sigma); rbl_ev2: compute_ev2 (:975-982) of two dense full-tree strategies from uniform
+ * beliefs -- out[0] = EV of strategy1 as player 0 against strategy2, out[1] = -(EV of strategy2 as player 0 against
+ * strategy1), as recursive_eval.cc:372 reports them. */
+int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out);
+int rbl_ev2(int device, int dice, int faces, const double* strategy1, const double* strategy2, double out[2]);
 /* compute_strategy_recursive (to_leaf = 0) / compute_strategy_recursive_to_leaf (1) (recursive_solving.cc:277-299) with
  * the engine's params and net: out = dense full-tree strategy [N_full][H][A], N_full = rbl_unroll_tree(.., -1, 0, 1<<20).
  * The frontier is solved level by level, all subgames of a level as lanes of one launch sequence. */

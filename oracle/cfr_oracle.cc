@@ -863,6 +863,39 @@ void orc_compute_exploitability2(int dice, int faces, const double* strategy, do
   }
 }
 
+void orc_compute_ev2(int dice, int faces, const double* strategy1, const double* strategy2, double out[2]) {
+  // compute_ev / compute_ev2, subgame_solving.cc:931-982: player 0 follows the first strategy, the opponent's reach comes
+  // from the second; terminal values as in the solvers; then the roles are swapped and the sign flipped.
+  Rules g(dice, faces);
+  Net none;
+  Traverser t(g, unroll(g, -1, 0, 1000000), none, false);
+  const int H = g.H, A = g.A;
+  const double* s[2] = {strategy1, strategy2};
+  for (int k = 0; k < 2; ++k) {
+    std::vector<double> mine(s[k], s[k] + (size_t)t.N * H * A), other(s[1 - k], s[1 - k] + (size_t)t.N * H * A);
+    std::vector<double> uniform(H, 1. / H);
+    t.sweep_reach(other, uniform.data(), 1, t.reach[1]);  // :943-944, opponent = player 1
+    t.leaf_values(0);                                      // terminal payoffs for player 0 (:949-954)
+    for (int n = t.N; n-- > 0;) {
+      const Node& nd = t.tree[n];
+      if (nd.cb == nd.ce) continue;
+      double* v = &t.value[(size_t)n * H];
+      for (int h = 0; h < H; ++h) v[h] = 0.0;
+      int lo, hi;
+      g.bid_range(nd.last_bid, &lo, &hi);
+      for (int c = nd.cb, a = lo; c < nd.ce; ++c, ++a) {
+        const double* cv = &t.value[(size_t)c * H];
+        if (nd.player == 0)
+          for (int h = 0; h < H; ++h) v[h] += mine[((size_t)n * H + h) * A + a] * cv[h];
+        else
+          for (int h = 0; h < H; ++h) v[h] += cv[h];
+      }
+    }
+    const double ev = seq_sum(&t.value[0], H) / H;
+    out[k] = k == 0 ? ev : -ev;
+  }
+}
+
 void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float* out, int64_t osize,
                        int num_actions) {
   synthetic_net(queries, rows, qsize, out, osize, num_actions);

@@ -100,6 +100,8 @@ class Oracle:
         L.orc_strategy_recursive_sampled.argtypes = [C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.c_int, NET_FN,
                                                      C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
         L.orc_strategy_recursive_sampled.restype = None
+        L.orc_compute_ev2.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_compute_ev2.restype = None
         L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                                         C.c_int]
         L.orc_synthetic_net.restype = None
@@ -185,6 +187,14 @@ class Oracle:
         s = np.ascontiguousarray(strategy, np.float64)
         out = np.zeros(2)
         self.lib.orc_compute_exploitability2(d, f, _dp(s), _dp(out))
+        return out
+
+    def ev2(self, d, f, strategy1, strategy2):
+        """compute_ev2 (subgame_solving.cc:975-982) of two dense full-tree strategies."""
+        a = np.ascontiguousarray(strategy1, np.float64)
+        b = np.ascontiguousarray(strategy2, np.float64)
+        out = np.zeros(2)
+        self.lib.orc_compute_ev2(d, f, _dp(a), _dp(b), _dp(out))
         return out
 
     # ---- solvers

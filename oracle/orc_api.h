@@ -79,6 +79,10 @@ void orc_strategy_recursive_sampled(int dice, int faces, const orc_params* param
 /* ---- full-tree evaluation (subgame_solving.cc:802-816): strategy dense [N_full][H][A] ---- */
 void orc_compute_exploitability2(int dice, int faces, const double* strategy, double out[2]);
 
+/* ---- compute_ev2 (subgame_solving.cc:931-982): expected value of playing strategy1 against strategy2 from uniform
+ *      beliefs, as player 0 (out[0]) and, with the roles swapped and the sign flipped, as player 1 (out[1]) ---- */
+void orc_compute_ev2(int dice, int faces, const double* strategy1, const double* strategy2, double out[2]);
+
 /* The synthetic belief net (a test double of ours; elementwise, exactly reproducible in IEEE float):
  *   v[h] = ((0.5f*q[2+A+h] - 0.25f*q[2+A+H+h]) + 0.125f*(q[1]-q[0])) + 0.0625f*q[2 + h % A]                      */
 void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float* out, int64_t osize, int num_actions);

@@ -285,6 +285,23 @@ void orc_compute_exploitability2(int dice, int faces, const double* strategy, do
   out[1] = e[1];
 }
 
+void orc_compute_ev2(int dice, int faces, const double* strategy1, const double* strategy2, double out[2]) {
+  Game game(dice, faces);
+  const auto tree = unroll_tree(game);
+  const int H = game.num_hands(), A = game.num_actions();
+  TreeStrategy s[2];
+  const double* src[2] = {strategy1, strategy2};
+  for (int k = 0; k < 2; ++k) {
+    init_nd((int)tree.size(), H, A, 0.0, &s[k]);
+    for (size_t n = 0; n < tree.size(); ++n)
+      for (int h = 0; h < H; ++h)
+        for (int a = 0; a < A; ++a) s[k][n][h][a] = src[k][(n * H + h) * A + a];
+  }
+  auto e = compute_ev2(game, s[0], s[1]);
+  out[0] = e[0];
+  out[1] = e[1];
+}
+
 void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float* out, int64_t osize,
                        int num_actions) {
   const int A = num_actions;

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_engine_timing", "rbl_engine_stats",
 ]
@@ -111,6 +111,8 @@ def lib():
         "rbl_solver_best_response": (C.c_int, [vp, C.c_int, dp]),
         "rbl_exploitability2": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp]),
         "rbl_strategy_recursive": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_solver_evaluate": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_ev2": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, dp]),
         "rbl_strategy_recursive_sampled": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_hand_values": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_examples": (C.c_int, [vp, C.c_int, fp, fp]),
@@ -168,6 +170,15 @@ def exploitability2(dice, faces, strategy, device=0):
     s = np.ascontiguousarray(strategy, np.float64)
     out = np.zeros(2)
     _check(lib().rbl_exploitability2(device, dice, faces, _p(s, C.c_double), _p(out, C.c_double)))
+    return out
+
+
+def ev2(dice, faces, strategy1, strategy2, device=0):
+    """compute_ev2 (subgame_solving.cc:975-982) of two dense full-tree strategies, on the GPU."""
+    a = np.ascontiguousarray(strategy1, np.float64)
+    b = np.ascontiguousarray(strategy2, np.float64)
+    out = np.zeros(2)
+    _check(lib().rbl_ev2(device, dice, faces, _p(a, C.c_double), _p(b, C.c_double), _p(out, C.c_double)))
     return out
 
 
@@ -290,6 +301,12 @@ class Engine:
     def best_response(self, traverser):
         out = np.zeros((self.B, self.H))
         _check(self.L.rbl_solver_best_response(self.h, traverser, _p(out, C.c_double)))
+        return out
+
+    def evaluate(self, traverser):
+        """compute_ev per lane: root values [B][H] of the traverser following the lane's current sigma."""
+        out = np.zeros((self.B, self.H))
+        _check(self.L.rbl_solver_evaluate(self.h, traverser, _p(out, C.c_double)))
         return out
 
     def strategy_recursive(self, to_leaf=False):

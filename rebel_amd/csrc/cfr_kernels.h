@@ -14,6 +14,7 @@ enum CfrMode : int {
   kModeQueries = 2,  // only (re)write queries for `next_trav` from the current sigma
   kModeBestResponse = 3,  // BRSolver::compute_br (subgame_solving.cc:316-358) against sigma; root values -> br_out
   kModeFpStep = 4,        // FP::step (subgame_solving.cc:433-476): sigma holds the AVERAGE strategy, regrets hold `last`
+  kModeEvaluate = 5,      // compute_ev (subgame_solving.cc:931-973): value of following sigma for the traverser -> br_out
 };
 
 // Everything the kernel needs; passed by value (fits the kernarg segment).

@@ -144,7 +144,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     int* t_parent = it, *t_act = it + N, *t_cb = it + 2 * N, *t_ce = it + 3 * N, *t_depth = it + 4 * N;
     int* t_leaves = it + 5 * N, *t_terms = t_leaves + v.L;
     int8_t* t_match = reinterpret_cast<int8_t*>(t_terms + v.T);
-    const bool br = a.mode == kModeBestResponse || a.mode == kModeFpStep;
+    const bool br = a.mode == kModeBestResponse || a.mode == kModeFpStep || a.mode == kModeEvaluate;
     const bool step = a.mode == kModeStep, load_sig = a.mode != kModeInit;
     const float* gv = a.values + (size_t)row_off * H;
     const int n_lv = ((step || br) && LDS) ? v.L * H : 0, n_mt = LDS ? a.faces * H : 0, n_tab = LDS ? N : 0;
@@ -217,9 +217,10 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
       }
   }
 
-  if (a.mode == kModeStep || a.mode == kModeBestResponse || a.mode == kModeFpStep) {
+  if (a.mode == kModeStep || a.mode == kModeBestResponse || a.mode == kModeFpStep || a.mode == kModeEvaluate) {
     const bool fp = a.mode == kModeFpStep;
     const bool br = a.mode == kModeBestResponse || fp;
+    const bool ev = a.mode == kModeEvaluate;  // policy evaluation: sum of sigma * value at the traverser's nodes, nothing updated
     const int t = a.trav;
     double* rho_t = t == 0 ? rho0 : rho1;
     const double* rho_o = t == 0 ? rho1 : rho0;
@@ -306,6 +307,10 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
             }
             if (fp)  // br_strategies as a one-hot over the node's edges (:345-348), kept in the staged `reg` rows
               for (int k = 0; k < cnt; ++k) reg[(c0 - 1 + k) * H + h] = k == best ? 1.0 : 0.0;
+          } else if (mine && ev) {  // compute_ev :955-962 (strategy * value, ascending actions)
+            const double* sc = sig + (c0 - 1) * H + h;
+            const int cnt = c1 - c0;
+            for (int k = 0; k < cnt; ++k) x += sc[k * H] * vc[k * H];
           } else if (mine) {
             const double* sc = sig + (c0 - 1) * H + h;
             double* rc = reg + (c0 - 1) * H + h;
@@ -333,7 +338,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
     }
 
     RBL_STAMP();  // 5: bottom-up
-    if (br && !fp) {
+    if ((br && !fp) || ev) {
       for (int h = threadIdx.x; h < H; h += blockDim.x) a.br_out[(size_t)lane * H + h] = val[h];
       return;
     }

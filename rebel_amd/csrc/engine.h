@@ -82,6 +82,7 @@ class Engine {
   void get_snapshot(int lane, double* out);
   void set_strategy(int lane, const double* dense);
   void best_response(int traverser, double* out);
+  void evaluate(int traverser, double* out);  // compute_ev: root values of following sigma, per lane [H]
   void hand_values(int lane, int player, double* out);
   void examples(int lane, float* queries, float* values);
   void get_queries(float* out);

@@ -665,6 +665,24 @@ void Engine::best_response(int traverser, double* out) {
   RBL_HIP_CHECK(hipMemcpy(out, d_br_.p, (size_t)B_ * g_.H * sizeof(double), hipMemcpyDeviceToHost));
 }
 
+// compute_ev (subgame_solving.cc:931-973) for every lane: the traverser follows the lane's sigma at its own nodes, the
+// opponent's reach is taken under the same sigma (set_strategy a mix of the two strategies to evaluate one against the
+// other); pseudo-leaves of depth-limited trees are valued by the engine's net like in best_response.
+void Engine::evaluate(int traverser, double* out) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (B_ == 0) throw std::runtime_error("evaluate: no lanes (call reset first)");
+  if (traverser != 0 && traverser != 1) throw std::runtime_error("evaluate: traverser must be 0 or 1");
+  if (d_br_.n < (size_t)max_lanes_ * g_.H) d_br_.alloc((size_t)max_lanes_ * g_.H);
+  if (rows_ > 0) {
+    launch(kModeQueries, 0, traverser, 0, 0, 1, 1, 1);
+    pending_trav_ = traverser;
+    run_net();
+  }
+  launch(kModeEvaluate, traverser, -1, 0, 0, 1, 1, 1);
+  sync();
+  RBL_HIP_CHECK(hipMemcpy(out, d_br_.p, (size_t)B_ * g_.H * sizeof(double), hipMemcpyDeviceToHost));
+}
+
 void Engine::get_snapshot(int lane, double* out) {
   check_lane(lane);
   if (!has_act_) throw std::runtime_error("get_snapshot: reset was called without act_iteration");
@@ -1229,6 +1247,36 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
       double s = 0;
       for (int h = 0; h < H; ++h) s += v[h];  // vector_sum (util.h:87-90)
       out[t] = s / H;
+    }
+  });
+}
+int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out) {
+  return guard([&] { e->impl.evaluate(traverser, out); });
+}
+int rbl_ev2(int device, int dice, int faces, const double* strategy1, const double* strategy2, double out[2]) {
+  return guard([&] {  // compute_ev2 (subgame_solving.cc:975-982): player 0 follows one strategy, player 1 the other
+    rbl_params p{};
+    p.num_iters = 1;
+    p.max_depth = 1000000;
+    p.use_cfr = 1;
+    rbl::Engine e(device, dice, faces, p, 1);
+    const rbl::Rules& g = e.rules();
+    const int H = g.H, A = g.A;
+    const std::vector<rbl::Node> full = rbl::unroll_tree(g, -1, 0, 1000000);
+    std::vector<double> b(2 * H, 1. / H), v(H), mix(full.size() * (size_t)H * A);
+    const int32_t rb = -1, rp = 0;
+    e.reset(1, &rb, &rp, b.data(), nullptr);
+    const double* s[2] = {strategy1, strategy2};
+    for (int k = 0; k < 2; ++k) {
+      for (size_t n = 0; n < full.size(); ++n) {
+        const double* src = (full[n].player == 0 ? s[k] : s[1 - k]) + n * (size_t)H * A;
+        std::copy(src, src + (size_t)H * A, mix.begin() + n * (size_t)H * A);
+      }
+      e.set_strategy(0, mix.data());
+      e.evaluate(0, v.data());
+      double sum = 0;
+      for (int h = 0; h < H; ++h) sum += v[h];  // vector_sum (util.h:87-90)
+      out[k] = k == 0 ? sum / H : -(sum / H);
     }
   });
 }

@@ -13,7 +13,8 @@ What it reproduces:
     reference's tensors), exploitability at 2^k repeats and at the end;
   * the machine-readable line `XXX {"net":..., "full_tree":..., "repeated toleaf N":...}` that scripts/eval_all.py:100-104
     greps for.
-Not reproduced: the EV-against-full-strategy (`YYY`) line, regret reports, strategy dumps, oracle-net mode.
+  * the `YYY {...}` line: EV of the full-tree strategy against each evaluated strategy (compute_ev2, rbl_ev2).
+Not reproduced: regret reports, strategy dumps, oracle-net mode.
 """
 import argparse
 import json
@@ -83,6 +84,8 @@ def main():
     ex = capi.exploitability2(d, f, full_strategy, a.device)
     print(f"Full FP exploitability: {(ex[0] + ex[1]) / 2:.6f} ({ex[0]:.6f},{ex[1]:.6f})")
     results = [("net", a.net), ("full_tree", "%.6f" % ((ex[0] + ex[1]) / 2))]
+    ev = capi.ev2(d, f, full_strategy, full_strategy, a.device)
+    results_ev = [("net", a.net), ("full_tree", "%.6f" % ((ev[0] + ev[1]) / 2))]
 
     if a.net:
         assert a.mdp_depth > 0, "--mdp_depth is required with --net"
@@ -108,11 +111,15 @@ def main():
             if ((sid + 1) & sid) == 0 or sid + 1 == a.num_repeats:
                 final = (summed / (reach_sum + np.float32(1e-6))).astype(np.float64)
                 ex = capi.exploitability2(d, f, final, a.device)
-                print("%5d: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1]))
+                ev = capi.ev2(d, f, full_strategy, final, a.device)  # compute_ev2(game, full_strategy, final_strategy), :370
+                print("%5d: %.6f (%.6f,%.6f)\tEV of full: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1],
+                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1]))
                 results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
+                results_ev.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
     for name, val in results[1:]:
         print(f" {name} {val}")
     print("XXX " + json.dumps(dict(results), separators=(", ", ":")))
+    print("YYY " + json.dumps(dict(results_ev), separators=(", ", ":")))
 
 
 if __name__ == "__main__":

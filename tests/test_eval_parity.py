@@ -90,6 +90,25 @@ def test_sampled_recursive_strategy_bit_exact(d, f, depth, iters, seed, root_onl
     assert not np.array_equal(got, e.strategy_recursive_sampled(seed + 1, root_only))
 
 
+@pytest.mark.parametrize("d,f", [(1, 4), (1, 5), (2, 2)])
+def test_ev2_bit_exact(d, f, port):
+    """compute_ev2 (subgame_solving.cc:931-982; the 'EV of full' numbers of recursive_eval): policy evaluation as a mode of
+    the CFR kernel, one strategy against another, bit-exact against the oracle."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    s1 = port.solver(d, f, orc.make_params(num_iters=24, max_depth=100000, linear_update=True, use_cfr=True))
+    s1.multistep()
+    s2 = port.solver(d, f, orc.make_params(num_iters=7, max_depth=100000, linear_update=False, use_cfr=True))
+    s2.multistep()
+    a, b = s1.get(orc.GET_AVERAGE), s2.get(orc.GET_LAST)
+    assert np.array_equal(capi.ev2(d, f, a, b), port.ev2(d, f, a, b))
+    assert np.array_equal(capi.ev2(d, f, b, a), port.ev2(d, f, b, a))
+    # a strategy against itself: zero-sum
+    e = capi.ev2(d, f, a, a)
+    assert abs(e[0] + e[1]) < 1e-12  # out[1] is minus the same expectation
+
+
 def test_recursive_eval_tool(tmp_path):
     """scripts/recursive_eval.py (the reference's recursive_eval CLI on the C ABI): runs, prints the XXX json line the
     reference's eval_all.py parses; with a subgame depth that covers the whole game the sampled strategies are last
@@ -109,3 +128,5 @@ def test_recursive_eval_tool(tmp_path):
     assert d["net"] == "zero" and float(d["full_tree"]) < 0.05
     assert float(d["repeated toleaf 8"]) < float(d["repeated toleaf 1"])
     assert "Iter=      64" in r.stdout
+    ev = json.loads([l for l in r.stdout.splitlines() if l.startswith("YYY ")][-1][4:])
+    assert set(ev) == set(d) and abs(float(ev["full_tree"])) < 1e-6  # EV of the full-tree strategy against itself

@@ -108,3 +108,17 @@ def test_sampled_recursive_strategy_port_vs_reference(d, f, depth, iters, seed, 
     a = ref.strategy_recursive_sampled(d, f, p, seed, root_only, net=net)
     o = port.strategy_recursive_sampled(d, f, p, seed, root_only, net=net)
     assert np.array_equal(a, o)
+
+
+@pytest.mark.parametrize("d,f", [(1, 3), (1, 4), (2, 2)])
+def test_ev2_port_vs_reference(d, f, ref, port):
+    """compute_ev2 (subgame_solving.cc:931-982): the port's restatement vs the reference, two unrelated strategies."""
+    from oracle import orc
+
+    s1 = port.solver(d, f, orc.make_params(num_iters=20, max_depth=100000, linear_update=True, use_cfr=True))
+    s1.multistep()
+    s2 = port.solver(d, f, orc.make_params(num_iters=5, max_depth=100000, linear_update=False, use_cfr=True))
+    s2.multistep()
+    a, b = s1.get(orc.GET_AVERAGE), s2.get(orc.GET_LAST)
+    assert np.array_equal(ref.ev2(d, f, a, b), port.ev2(d, f, a, b))
+    assert np.array_equal(ref.ev2(d, f, b, a), port.ev2(d, f, b, a))
