@@ -58,6 +58,12 @@ def test_mlp_vs_float64_reference(d, f, hidden, layers_n, use_ln, rows):
     _check_mlp(d, f, hidden, layers_n, use_ln, rows)
 
 
+def test_mlp_edge_batches():
+    """Empty batch, a single row, one row short of / one row past a 64-row group, and exactly one group per CU + 1 row."""
+    for rows in (0, 1, 63, 65, 64 * 256 + 1):
+        _check_mlp(1, 6, 256, 2, True, rows)
+
+
 @pytest.mark.parametrize("tile", [3, 4, 2, 0])
 def test_mlp_kernel_variants(tile, monkeypatch):
     """The older kernel variants stay selectable (RBL_MLP_TILE) and are the fallback for shapes the resident kernel does
@@ -89,6 +95,9 @@ def _check_mlp(d, f, hidden, layers_n, use_ln, rows):
     q[:, 2 + e.A:2 + e.A + H] = rng.dirichlet(np.ones(H), rows)
     q[:, 2 + e.A + H:] = rng.dirichlet(np.ones(H), rows)
     y = e.net_forward(q)
+    assert y.shape == (rows, H)
+    if rows == 0:
+        return
     ref = _np_net(q, layers, ln, w_out, b_out)
     assert np.abs(ref).max() > 0.05  # O(0.1-1) outputs: the tolerance is meaningful
     assert np.abs(y - ref).max() <= ATOL, np.abs(y - ref).max()
