@@ -15,6 +15,8 @@
 // the bit-exactness contract with the reference (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py
 // runs against this kernel.  Only kModeStep of LDS-resident lanes runs here; init / query-only / best-response / FP
 // modes and big trees stay on the generic kernel (they share the global state layout).
+#include <type_traits>
+
 #include "cfr_kernels.h"
 
 namespace rbl {
@@ -52,17 +54,23 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // The lane's strategy and regrets are requested BEFORE its shape is known (their addresses only depend on the lane; the
   // bound is the slab size, the real extent is applied at the LDS store): the shape look-up (lane -> shape id -> shape
   // record -> tables) is a chain of dependent loads, and the state comes from Infinity Cache / HBM, not from L2.
-  constexpr int kB = H <= 6 ? 5 : 7;  // strides of blockDim = 128 that cover the depth-2 root tree (E * H = 540 / 810)
-  double s_[kB], r_[kB];
+  // (even H: rows are 16-byte aligned, the state moves as double2)
+  constexpr int kW = H % 2 == 0 ? 2 : 1;                        // doubles per transfer
+  constexpr int kB = H % 2 == 0 ? 3 : (H <= 6 ? 5 : 7);         // strides of blockDim = 128 that cover the depth-2 root tree
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  typedef typename std::conditional<kW == 2, d2_t, double>::type dw;
+  dw s_[kB], r_[kB];
   {
     const size_t le = (size_t)lane * a.Emax * H;
-    const int cap = a.Emax * H;
+    const int cap = a.Emax * H / kW;
+    const dw* gs = reinterpret_cast<const dw*>(a.sigma + le);
+    const dw* gr = reinterpret_cast<const dw*>(a.regrets + le);
 #pragma unroll
     for (int u = 0; u < kB; ++u) {
       const int i = tid + u * nthr;
       if (i < cap) {
-        s_[u] = a.sigma[le + i];
-        r_[u] = a.regrets[le + i];
+        s_[u] = gs[i];
+        r_[u] = gr[i];
       }
     }
   }
@@ -124,28 +132,38 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       tl = gl[tid];
     }
     if (tid < FACES * H) tm = a.matches[tid];
-    float v_[kB];
+    constexpr int kV = H <= 6 ? 4 : 5;  // strides that cover the root's L * H leaf values (396 / 594)
+    float v_[kV];
 #pragma unroll
-    for (int u = 0; u < kB; ++u) {
+    for (int u = 0; u < kV; ++u) {
       const int i = tid + u * nthr;
       if (i < LH) v_[u] = gv[i];
     }
+    {
+      dw* lsig = reinterpret_cast<dw*>(sig);
+      dw* lreg = reinterpret_cast<dw*>(reg);
+      const dw* gs = reinterpret_cast<const dw*>(g_sig);
+      const dw* gr = reinterpret_cast<const dw*>(g_reg);
+      const int EW = EH / kW;  // E * H is even whenever kW == 2
 #pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const int i = tid + u * nthr;
-      if (i < EH) {
-        sig[i] = s_[u];
-        reg[i] = r_[u];
+      for (int u = 0; u < kB; ++u) {
+        const int i = tid + u * nthr;
+        if (i < EW) {
+          lsig[i] = s_[u];
+          lreg[i] = r_[u];
+        }
       }
+      for (int i = tid + kB * nthr; i < EW; i += nthr) {  // what the first kB strides did not cover
+        lsig[i] = gs[i];
+        lreg[i] = gr[i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kV; ++u) {
+      const int i = tid + u * nthr;
       if (i < LH) lvals[i] = v_[u];
     }
-    for (int i = tid + kB * nthr; i < max(EH, LH); i += nthr) {  // what the first kB strides did not cover
-      if (i < EH) {
-        sig[i] = g_sig[i];
-        reg[i] = g_reg[i];
-      }
-      if (i < LH) lvals[i] = gv[i];
-    }
+    for (int i = tid + kV * nthr; i < LH; i += nthr) lvals[i] = gv[i];
     for (int i = tid; i < N; i += nthr) {  // N <= blockDim for every supported game except on the second lap
       if (i != tid) {
         tp = gp[i];
@@ -371,19 +389,47 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       if ((root_player ^ (t_depth[p] & 1)) == t) {
         const Row<H> rp = load_row<H>(rho_t + t_irank[p] * H);
         const Row<H> rg = load_row<H>(reg + e);
+        if constexpr (H % 2 == 0) {  // rows are 16-byte aligned: half as many global instructions
+          typedef double d2 __attribute__((ext_vector_type(2)));
+          d2* gs = reinterpret_cast<d2*>(g_sum + e);
+          d2* gg = reinterpret_cast<d2*>(g_sig + e);
+          d2* gr = reinterpret_cast<d2*>(g_reg + e);
+          d2 acc2[H / 2];
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-          double x = g_sum[e + h];
-          x *= a.strat;
-          x += rp.v[h] * s.v[h];
-          g_sum[e + h] = x;
-          g_sig[e + h] = s.v[h];
-          g_reg[e + h] = rg.v[h];
+          for (int h = 0; h < H / 2; ++h) acc2[h] = gs[h];
+#pragma unroll
+          for (int h = 0; h < H / 2; ++h) {
+            double x0 = acc2[h][0], x1 = acc2[h][1];
+            x0 *= a.strat;
+            x1 *= a.strat;
+            x0 += rp.v[2 * h] * s.v[2 * h];
+            x1 += rp.v[2 * h + 1] * s.v[2 * h + 1];
+            gs[h] = d2{x0, x1};
+            gg[h] = d2{s.v[2 * h], s.v[2 * h + 1]};
+            gr[h] = d2{rg.v[2 * h], rg.v[2 * h + 1]};
+          }
+        } else {
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            double x = g_sum[e + h];
+            x *= a.strat;
+            x += rp.v[h] * s.v[h];
+            g_sum[e + h] = x;
+            g_sig[e + h] = s.v[h];
+            g_reg[e + h] = rg.v[h];
+          }
         }
       }
       if (snap_now) {
+        if constexpr (H % 2 == 0) {
+          typedef double d2 __attribute__((ext_vector_type(2)));
+          d2* sn = reinterpret_cast<d2*>(snap + e);
 #pragma unroll
-        for (int h = 0; h < H; ++h) snap[e + h] = s.v[h];
+          for (int h = 0; h < H / 2; ++h) sn[h] = d2{s.v[2 * h], s.v[2 * h + 1]};
+        } else {
+#pragma unroll
+          for (int h = 0; h < H; ++h) snap[e + h] = s.v[h];
+        }
       }
     }
   }
