@@ -47,9 +47,6 @@ template <int H, int A, int DICE, int FACES>
 __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
-  // children whose rows are requested together in the per-node passes.  2 and 4 were measured (MI355X, 1dx6f root): the
-  // step does not get shorter (the chain is the dependent fp64 adds, not the LDS reads) and 4 doubles the VGPR count
-  constexpr int kCh = 1;
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   // The lane's strategy and regrets are requested BEFORE its shape is known (their addresses only depend on the lane; the
   // bound is the slab size, the real extent is applied at the LDS store): the shape look-up (lane -> shape id -> shape
@@ -277,26 +274,20 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       Row<H> x;
 #pragma unroll
       for (int h = 0; h < H; ++h) x.v[h] = 0.0;
-      // children in batches of kCh, accumulated in ascending order
-      for (int c = c0; c < c1; c += kCh) {
-        Row<H> vc[kCh], sc[kCh];
+      // ascending order over the actions; `mine` is uniform, so it selects the loop, not a branch inside it (with the test
+      // in the body hipcc kept two copies of the accumulator row and moved one into the other every iteration)
+      if (mine) {
+        for (int c = c0; c < c1; ++c) {
+          const Row<H> vc = load_row<H>(val + c * H), sc = load_row<H>(sig + (c - 1) * H);
 #pragma unroll
-        for (int u = 0; u < kCh; ++u)
-          if (c + u < c1) {
-            vc[u] = load_row<H>(val + (c + u) * H);
-            if (mine) sc[u] = load_row<H>(sig + (c + u - 1) * H);
-          }
+          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h] * sc.v[h];
+        }
+      } else {
+        for (int c = c0; c < c1; ++c) {
+          const Row<H> vc = load_row<H>(val + c * H);
 #pragma unroll
-        for (int u = 0; u < kCh; ++u)
-          if (c + u < c1) {
-            if (mine) {
-#pragma unroll
-              for (int h = 0; h < H; ++h) x.v[h] += vc[u].v[h] * sc[u].v[h];
-            } else {
-#pragma unroll
-              for (int h = 0; h < H; ++h) x.v[h] += vc[u].v[h];
-            }
-          }
+          for (int h = 0; h < H; ++h) x.v[h] += vc.v[h];
+        }
       }
       store_row<H>(val + n * H, x);
     }
@@ -324,17 +315,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       Row<H> s;
 #pragma unroll
       for (int h = 0; h < H; ++h) s.v[h] = 0.0;
-      for (int c = c0; c < c1; c += kCh) {
-        Row<H> mc[kCh];
+      for (int c = c0; c < c1; ++c) {
+        const Row<H> mc = load_row<H>(sig + (c - 1) * H);
 #pragma unroll
-        for (int u = 0; u < kCh; ++u)
-          if (c + u < c1) mc[u] = load_row<H>(sig + (c + u - 1) * H);
-#pragma unroll
-        for (int u = 0; u < kCh; ++u)
-          if (c + u < c1) {
-#pragma unroll
-            for (int h = 0; h < H; ++h) s.v[h] += mc[u].v[h];
-          }
+        for (int h = 0; h < H; ++h) s.v[h] += mc.v[h];
       }
       store_row<H>(rho_t + t_irank[n] * H, s);
     }
