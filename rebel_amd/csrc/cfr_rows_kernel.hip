@@ -203,11 +203,11 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       for (int h = 0; h < H; ++h) {  // b[m[h]] += r, without dynamic register indexing (x + 0.0 == x for x >= +0)
         const int mh = m[h];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;
+        for (int k = 0; k <= DICE; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;  // one hand shows at most DICE matches
         s += ro.v[h];
       }
 #pragma unroll
-      for (int k = NB - 2; k >= 0; --k) b[k] += b[k + 1];
+      for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];  // bins above DICE are +0.0: adding them changes no bit
       const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
