@@ -422,9 +422,9 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
   if (a.next_trav >= 0 && L > 0) {
     __syncthreads();  // val / reg are dead from here on: their bytes stage the query rows
-    const int* gleaves = a.leaves + sh.leaf_off;
-    for (int k = tid; k < L; k += nthr) {
-      const int n = gleaves[k];
+    for (int n = tid; n < N; n += nthr) {  // a pseudo-leaf's thread writes its row (no look-up of the global leaf list)
+      const int k = t_lrow[n];
+      if (k < 0) continue;
       float* q = qstage + k * Q;
       Row<H> r0, r1;
       const int ir = t_irank[n];
