@@ -63,12 +63,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     const dw* gs = reinterpret_cast<const dw*>(a.sigma + le);
     const dw* gr = reinterpret_cast<const dw*>(a.regrets + le);
 #pragma unroll
-    for (int u = 0; u < kB; ++u) {
-      const int i = tid + u * nthr;
-      if (i < cap) {
-        s_[u] = gs[i];
-        r_[u] = gr[i];
-      }
+    for (int u = 0; u < kB; ++u) {  // index clamped instead of predicated: no exec juggling, no phi copies
+      const int i = min(tid + u * nthr, cap - 1);
+      s_[u] = gs[i];
+      r_[u] = gr[i];
     }
   }
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
@@ -117,24 +115,14 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     const int EH = E * H, LH = L * H;
     // every global load is issued before the first LDS store (a plain "load, store, next i" loop paid one memory round
     // trip per stride: 5 for the root tree at 128 threads, a third of the whole step)
-    int tp = 0, ta = 0, tb = 0, te = 0, td = 0, ti = 0, tl = 0;
-    int8_t tm = 0;
-    if (tid < N) {
-      tp = gp[tid];
-      ta = ga[tid];
-      tb = gb[tid];
-      te = ge[tid];
-      td = gd[tid];
-      ti = gi[tid];
-      tl = gl[tid];
-    }
-    if (tid < FACES * H) tm = a.matches[tid];
+    const int nn = min(tid, N - 1);  // clamped, unpredicated loads; the stores below apply the real bounds
+    int tp = gp[nn], ta = ga[nn], tcb = gb[nn], te = ge[nn], td = gd[nn], ti = gi[nn], tl = gl[nn];
+    const int8_t tm = a.matches[min(tid, FACES * H - 1)];
     constexpr int kV = H <= 6 ? 4 : 5;  // strides that cover the root's L * H leaf values (396 / 594)
     float v_[kV];
+    if (LH > 0) {  // uniform
 #pragma unroll
-    for (int u = 0; u < kV; ++u) {
-      const int i = tid + u * nthr;
-      if (i < LH) v_[u] = gv[i];
+      for (int u = 0; u < kV; ++u) v_[u] = gv[min(tid + u * nthr, LH - 1)];
     }
     {
       dw* lsig = reinterpret_cast<dw*>(sig);
@@ -161,25 +149,26 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       if (i < LH) lvals[i] = v_[u];
     }
     for (int i = tid + kV * nthr; i < LH; i += nthr) lvals[i] = gv[i];
-    for (int i = tid; i < N; i += nthr) {  // N <= blockDim for every supported game except on the second lap
-      if (i != tid) {
-        tp = gp[i];
-        ta = ga[i];
-        tb = gb[i];
-        te = ge[i];
-        td = gd[i];
-        ti = gi[i];
-        tl = gl[i];
-      }
-      t_parent[i] = tp;
-      t_act[i] = ta;
-      t_cb[i] = tb;
-      t_ce[i] = te;
-      t_depth[i] = td;
-      t_irank[i] = ti;
-      t_lrow[i] = tl;
+    if (tid < N) {
+      t_parent[tid] = tp;
+      t_act[tid] = ta;
+      t_cb[tid] = tcb;
+      t_ce[tid] = te;
+      t_depth[tid] = td;
+      t_irank[tid] = ti;
+      t_lrow[tid] = tl;
     }
-    for (int i = tid; i < FACES * H; i += nthr) t_match[i] = i == tid ? tm : a.matches[i];
+    for (int i = tid + nthr; i < N; i += nthr) {  // trees wider than the block (64-thread launches, deeper subgames)
+      t_parent[i] = gp[i];
+      t_act[i] = ga[i];
+      t_cb[i] = gb[i];
+      t_ce[i] = ge[i];
+      t_depth[i] = gd[i];
+      t_irank[i] = gi[i];
+      t_lrow[i] = gl[i];
+    }
+    if (tid < FACES * H) t_match[tid] = tm;
+    for (int i = tid + nthr; i < FACES * H; i += nthr) t_match[i] = a.matches[i];
     if (tid < H) {
       rho0[tid] = bel[tid];
       rho1[tid] = bel[H + tid];
