@@ -225,23 +225,29 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   for (int lev = 1; lev < nlev; ++lev) {
     const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
     const int mover = root_player ^ ((lev - 1) & 1);
+    // the mover of the parents is uniform per level: it picks POINTERS (whose row is multiplied by sigma, whose row a leaf
+    // needs), not registers -- with `if (mover == 0) r0 *= s else r1 *= s` and `opp == 0 ? r0 : r1` on register rows hipcc
+    // kept both variants alive and selected element by element (12 v_cndmask + 6 copies per node)
+    double* rho_m = mover == 0 ? rho0 : rho1;  // reach of the player who acted
+    double* rho_n = mover == 0 ? rho1 : rho0;  // reach of the other one: copied
     for (int n = n0 + tid; n < n1; n += nthr) {
       const int pr = t_irank[t_parent[n]];
-      Row<H> r0 = load_row<H>(rho0 + pr * H), r1 = load_row<H>(rho1 + pr * H);
-      const Row<H> s = load_row<H>(sig + (n - 1) * H);
-      if (mover == 0) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) r0.v[h] = r0.v[h] * s.v[h];
-      } else {
-#pragma unroll
-        for (int h = 0; h < H; ++h) r1.v[h] = r1.v[h] * s.v[h];
-      }
       const int ir = t_irank[n];
       if (ir >= 0) {
-        store_row<H>(rho0 + ir * H, r0);
-        store_row<H>(rho1 + ir * H, r1);
+        Row<H> rm = load_row<H>(rho_m + pr * H);
+        const Row<H> rn = load_row<H>(rho_n + pr * H), s = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * s.v[h];
+        store_row<H>(rho_m + ir * H, rm);
+        store_row<H>(rho_n + ir * H, rn);
+      } else if (mover == opp) {  // a leaf only needs the opponent's reach
+        Row<H> ro = load_row<H>(rho_m + pr * H);
+        const Row<H> s = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) ro.v[h] = ro.v[h] * s.v[h];
+        leaf_value(n, ro);
       } else {
-        leaf_value(n, opp == 0 ? r0 : r1);
+        leaf_value(n, load_row<H>(rho_n + pr * H));
       }
     }
     __syncthreads();
@@ -415,38 +421,39 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       const int k = t_lrow[n];
       if (k < 0) continue;
       float* q = qstage + k * Q;
-      Row<H> r0, r1;
+      // rm: reach of the player who acted at the parent (times sigma), rn: the other player's (copied); which of the two is
+      // player 0 only decides WHERE in the row they are written (a per-thread offset, not a per-element register select)
+      Row<H> rm, rn;
+      int pm = 0;  // player whose reach is rm
       const int ir = t_irank[n];
       if (ir >= 0) {  // only the root can be a pseudo-leaf with a stored row (max_depth = 0)
-        r0 = load_row<H>(rho0 + ir * H);
-        r1 = load_row<H>(rho1 + ir * H);
+        rm = load_row<H>(rho0 + ir * H);
+        rn = load_row<H>(rho1 + ir * H);
       } else {
         const int p = t_parent[n], pr = t_irank[p];
-        r0 = load_row<H>(rho0 + pr * H);
-        r1 = load_row<H>(rho1 + pr * H);
+        pm = root_player ^ (t_depth[p] & 1);
+        rm = load_row<H>((pm == 0 ? rho0 : rho1) + pr * H);
+        rn = load_row<H>((pm == 0 ? rho1 : rho0) + pr * H);
         const Row<H> s = load_row<H>(sig + (n - 1) * H);
-        if ((root_player ^ (t_depth[p] & 1)) == 0) {
 #pragma unroll
-          for (int h = 0; h < H; ++h) r0.v[h] = r0.v[h] * s.v[h];
-        } else {
-#pragma unroll
-          for (int h = 0; h < H; ++h) r1.v[h] = r1.v[h] * s.v[h];
-        }
+        for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * s.v[h];
       }
-      double s0 = 0, s1 = 0;
+      double sm = 0, sn = 0;
 #pragma unroll
-      for (int h = 0; h < H; ++h) s0 += r0.v[h] + kEps;  // normalize_probabilities_safe (util.h:68-78)
+      for (int h = 0; h < H; ++h) sm += rm.v[h] + kEps;  // normalize_probabilities_safe (util.h:68-78)
 #pragma unroll
-      for (int h = 0; h < H; ++h) s1 += r1.v[h] + kEps;
+      for (int h = 0; h < H; ++h) sn += rn.v[h] + kEps;
       q[0] = (float)(root_player ^ (t_depth[n] & 1));
       q[1] = (float)a.next_trav;
       const int lb = t_act[n];
 #pragma unroll
       for (int j = 0; j < A; ++j) q[2 + j] = (j == lb) ? 1.0f : 0.0f;
+      float* qm = q + 2 + A + pm * H;
+      float* qn = q + 2 + A + (1 - pm) * H;
 #pragma unroll
-      for (int h = 0; h < H; ++h) q[2 + A + h] = (float)((r0.v[h] + kEps) / s0);
+      for (int h = 0; h < H; ++h) qm[h] = (float)((rm.v[h] + kEps) / sm);
 #pragma unroll
-      for (int h = 0; h < H; ++h) q[2 + A + H + h] = (float)((r1.v[h] + kEps) / s1);
+      for (int h = 0; h < H; ++h) qn[h] = (float)((rn.v[h] + kEps) / sn);
     }
     __syncthreads();
     float* gq = a.queries + (size_t)row_off * Q;
