@@ -198,14 +198,24 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
 #pragma unroll
       for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];  // bins above DICE are +0.0: adding them changes no bit
       const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
+      // hands with the same number of matches need the same entry b[max(0, qty - matches)]: DICE + 1 candidates are picked
+      // once per node, then each hand selects among those (instead of a 2 * DICE deep select chain per hand)
+      double cand[DICE + 1];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const int left = max(0, qty - (int)m[h]);
+      for (int mm = 0; mm <= DICE; ++mm) {
+        const int left = max(0, qty - mm);
         double bl = b[0];
 #pragma unroll
         for (int k = 1; k < NB; ++k) bl = (left == k) ? b[k] : bl;
-        double x = (double)(float)bl * 2 - s;  // fp32 truncation (:785)
-        if (inverse) x *= -1.0;
+        cand[mm] = (double)(float)bl * 2 - s;  // fp32 truncation (:785)
+        if (inverse) cand[mm] *= -1.0;
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mh = m[h];
+        double x = cand[0];
+#pragma unroll
+        for (int mm = 1; mm <= DICE; ++mm) x = (mh == mm) ? cand[mm] : x;
         out.v[h] = x;
       }
     } else {
