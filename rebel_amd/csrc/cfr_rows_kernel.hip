@@ -69,9 +69,15 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       r_[u] = gr[i];
     }
   }
-  const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
-  const int N = sh.N, E = N - 1, L = sh.L, NI = sh.NI, nlev = sh.nlev;
-  const int root_player = a.lane_root_player[lane], row_off = a.lane_row_off[lane];
+  // Lane descriptors and the shape record are read-only for the whole launch: read them through the constant address
+  // space so that they are SCALAR loads.  As plain global pointers hipcc fetched sh.node_off with a vector load +
+  // readfirstlane, and the vmcnt(0) in front of the readfirstlane also waited for the speculative state loads above
+  // (vmcnt retires in order): the table addresses could not even be formed before the state had arrived.
+  typedef const int __attribute__((address_space(4)))* cint_p;
+  typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
+  const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
+  const int N = shc->N, E = N - 1, L = shc->L, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
+  const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
   const int t = a.trav, opp = 1 - t;
 
   // ---- LDS layout (doubles): rho0, rho1 [NI][H] | sig [E][H] | val [N][H] | reg [E][H] | leaf values | tables
@@ -104,13 +110,13 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   RBL_STAMP();  // 0: start
   // ---------------------------------------------------------------- stage (flat, coalesced)
   {
-    const int* gp = a.parent + sh.node_off;
-    const int* ga = a.act + sh.node_off;
-    const int* gb = a.cb + sh.node_off;
-    const int* ge = a.ce + sh.node_off;
-    const int* gd = a.depth + sh.node_off;
-    const int* gi = a.irank + sh.node_off;
-    const int* gl = a.leaf_row + sh.node_off;
+    const int* gp = a.parent + node_off;
+    const int* ga = a.act + node_off;
+    const int* gb = a.cb + node_off;
+    const int* ge = a.ce + node_off;
+    const int* gd = a.depth + node_off;
+    const int* gi = a.irank + node_off;
+    const int* gl = a.leaf_row + node_off;
     const float* gv = a.values + (size_t)row_off * H;
     const int EH = E * H, LH = L * H;
     // every global load is issued before the first LDS store (a plain "load, store, next i" loop paid one memory round
@@ -233,7 +239,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // rows are stored for nodes with children, leaves turn theirs into a value right away
   if (tid == 0 && t_cb[0] == t_ce[0]) leaf_value(0, load_row<H>(opp == 0 ? rho0 : rho1));
   for (int lev = 1; lev < nlev; ++lev) {
-    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const int mover = root_player ^ ((lev - 1) & 1);
     // the mover of the parents is uniform per level: it picks POINTERS (whose row is multiplied by sigma, whose row a leaf
     // needs), not registers -- with `if (mover == 0) r0 *= s else r1 *= s` and `opp == 0 ? r0 : r1` on register rows hipcc
@@ -270,8 +276,8 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // matching (:619-634) and the regret discount (:639-650)
   double* rho_t = t == 0 ? rho0 : rho1;
   for (int lev = nlev - 2; lev >= 0; --lev) {
-    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
-    const int c_lo = sh.lev_off[lev + 1], c_hi = sh.lev_off[lev + 2];
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
+    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
     const bool mine = (root_player ^ (lev & 1)) == t;
     for (int n = n0 + tid; n < n1; n += nthr) {  // node value: sequential over the actions
       const int c0 = t_cb[n], c1 = t_ce[n];
@@ -351,7 +357,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638), rows
   // of nodes with children only
   for (int lev = 1; lev < nlev - 1; ++lev) {
-    const int n0 = sh.lev_off[lev], n1 = sh.lev_off[lev + 1];
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const bool own = (root_player ^ ((lev - 1) & 1)) == t;
     for (int n = n0 + tid; n < n1; n += nthr) {
       const int ir = t_irank[n];
