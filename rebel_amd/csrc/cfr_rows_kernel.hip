@@ -108,6 +108,8 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     ++dbg_k;                                                           \
   } while (0)
   RBL_STAMP();  // 0: start
+  double bel_t = 0.0, rmean_t = 0.0;  // threads < H: the traverser's root belief and running root value mean of hand tid
+  const bool snap_now = a.lane_act_iter && ((cint_p)a.lane_act_iter)[lane] == a.steps_after;
   // ---------------------------------------------------------------- stage (flat, coalesced)
   {
     const int* gp = a.parent + node_off;
@@ -176,8 +178,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     if (tid < FACES * H) t_match[tid] = tm;
     for (int i = tid + nthr; i < FACES * H; i += nthr) t_match[i] = a.matches[i];
     if (tid < H) {
-      rho0[tid] = bel[tid];
-      rho1[tid] = bel[H + tid];
+      bel_t = bel[t * H + tid];
+      rho0[tid] = t == 0 ? bel_t : bel[tid];
+      rho1[tid] = t == 1 ? bel_t : bel[H + tid];
+      rmean_t = rmean[t * H + tid];  // used after the bottom-up sweep: requested now, not in front of a barrier there
     }
     __syncthreads();
   }
@@ -347,10 +351,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   RBL_STAMP();  // 5: bottom-up
   // ---------------------------------------------------------------- running mean of the root values (:579-590)
   if (tid < H) {
-    double m = rmean[t * H + tid];
+    double m = rmean_t;
     m += (val[tid] - m) * a.alpha;
     rmean[t * H + tid] = m;
-    rho_t[tid] = bel[t * H + tid];  // root row of the traverser (it served as scratch above)
+    rho_t[tid] = bel_t;  // root row of the traverser (it served as scratch above)
   }
   __syncthreads();
 
@@ -376,7 +380,6 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   RBL_STAMP();  // 6: new reach
   // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
   {
-    const bool snap_now = a.lane_act_iter && a.lane_act_iter[lane] == a.steps_after;
     double* snap = a.snapshot + lane_e;
     for (int c = 1 + tid; c < N; c += nthr) {
       const int p = t_parent[c], e = (c - 1) * H;
