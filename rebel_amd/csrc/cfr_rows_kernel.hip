@@ -433,6 +433,24 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   }
 
   RBL_STAMP();  // 7: write-back
+  // (x + eps) / s for the H elements of a row, bit-identical to H IEEE divisions: this IS hipcc's f64 division sequence
+  // (v_rcp_f64, two Newton steps on the reciprocal, q0 = a y, r = a - s q0, q = q0 + r y) with the part that only depends
+  // on the denominator done once per row.  What is left out -- v_div_scale and v_div_fixup -- is the identity here: both
+  // only act when the operands' exponents are >= 768 apart, denormal, zero, infinite or NaN, and 1e-80 <= a <= s <= H + 1.
+  auto norm_row = [&](const Row<H>& r, double ssum, float* dst) {
+    double y = __builtin_amdgcn_rcp(ssum);
+    double e = __builtin_fma(-ssum, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-ssum, y, 1.0);
+    y = __builtin_fma(y, e, y);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const double num = r.v[h] + kEps;
+      const double q0 = num * y;
+      const double rem = __builtin_fma(-ssum, q0, num);
+      dst[h] = (float)__builtin_fma(rem, y, q0);
+    }
+  };
   // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
   if (a.next_trav >= 0 && L > 0) {
     __syncthreads();  // val / reg are dead from here on: their bytes stage the query rows
@@ -469,10 +487,8 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       for (int j = 0; j < A; ++j) q[2 + j] = (j == lb) ? 1.0f : 0.0f;
       float* qm = q + 2 + A + pm * H;
       float* qn = q + 2 + A + (1 - pm) * H;
-#pragma unroll
-      for (int h = 0; h < H; ++h) qm[h] = (float)((rm.v[h] + kEps) / sm);
-#pragma unroll
-      for (int h = 0; h < H; ++h) qn[h] = (float)((rn.v[h] + kEps) / sn);
+      norm_row(rm, sm, qm);
+      norm_row(rn, sn, qn);
     }
     __syncthreads();
     float* gq = a.queries + (size_t)row_off * Q;
