@@ -80,10 +80,11 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
   const int t = a.trav, opp = 1 - t;
 
-  // ---- LDS layout (doubles): rho0, rho1 [NI][H] | sig [E][H] | val [N][H] | reg [E][H] | leaf values | tables
+  // ---- LDS layout (doubles): rho0, rho1, yrow [NI][H] | sig [E][H] | val [N][H] | reg [E][H] | leaf values | tables
   double* rho0 = lds;
   double* rho1 = rho0 + NI * H;
-  double* sig = rho1 + NI * H;
+  double* yrow = rho1 + NI * H;  // refined reciprocals of the regret-matching row sums (see the normalisation pass)
+  double* sig = yrow + NI * H;
   double* val = sig + E * H;
   double* reg = val + N * H;
   float* lvals = reinterpret_cast<float*>(reg + E * H);
@@ -335,14 +336,32 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) s.v[h] += mc.v[h];
       }
+      // m / s below is hipcc's f64 division sequence with its denominator-only part (v_rcp_f64 + two Newton steps) done here,
+      // once per node instead of once per edge, and without v_div_scale / v_div_fixup, which are the identity for these
+      // operands (1e-80 <= m <= s, exponents < 768 apart; scripts/micro/div_shared_rcp.hip checks 3e9 cases against `/`)
+      Row<H> y;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        double yy = __builtin_amdgcn_rcp(s.v[h]);
+        double e = __builtin_fma(-s.v[h], yy, 1.0);
+        yy = __builtin_fma(yy, e, yy);
+        e = __builtin_fma(-s.v[h], yy, 1.0);
+        y.v[h] = __builtin_fma(yy, e, yy);
+      }
       store_row<H>(rho_t + t_irank[n] * H, s);
+      store_row<H>(yrow + t_irank[n] * H, y);
     }
     __syncthreads();
     for (int c = c_lo + tid; c < c_hi; c += nthr) {
-      const Row<H> s = load_row<H>(rho_t + t_irank[t_parent[c]] * H);
+      const int pr = t_irank[t_parent[c]];
+      const Row<H> s = load_row<H>(rho_t + pr * H), y = load_row<H>(yrow + pr * H);
       Row<H> m = load_row<H>(sig + (c - 1) * H);
 #pragma unroll
-      for (int h = 0; h < H; ++h) m.v[h] = m.v[h] / s.v[h];
+      for (int h = 0; h < H; ++h) {
+        const double q0 = m.v[h] * y.v[h];
+        const double rem = __builtin_fma(-s.v[h], q0, m.v[h]);
+        m.v[h] = __builtin_fma(rem, y.v[h], q0);
+      }
       store_row<H>(sig + (c - 1) * H, m);
     }
     __syncthreads();
@@ -501,7 +520,7 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
 }  // namespace
 
 size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces) {
-  size_t d = (size_t)2 * NI * H + (size_t)(N - 1) * H + (size_t)N * H + (size_t)(N - 1) * H;  // doubles
+  size_t d = (size_t)3 * NI * H + (size_t)(N - 1) * H + (size_t)N * H + (size_t)(N - 1) * H;  // doubles
   size_t b = d * 8 + (size_t)((L * H + 3) & ~3) * 4 + (size_t)7 * N * 4 + (size_t)faces * H;
   return (b + 15) & ~(size_t)15;
 }
