@@ -5,7 +5,9 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -1077,10 +1079,20 @@ int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
   }
   std::vector<int32_t> root_bid(bid_), root_player(player_);
   std::vector<double> root_beliefs(beliefs_);
+  const bool trace = env_int("RBL_DEBUG_EPOCH", 0) != 0;  // host-side phase times of one epoch on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t0 = now();
   e_->reset(n_, bid_.data(), player_.data(), beliefs_.data(), act_.data());
+  const auto t1 = now();
   e_->multistep(num_iters);
+  if (trace) e_->sync();
+  const auto t2 = now();
   const double *snap_p = nullptr, *rmean_p = nullptr;
   e_->read_snapshots(&snap_p, &rmean_p);
+  const auto t3 = now();
   const size_t eh = (size_t)e_->emax() * H;
   ex_q_.resize((size_t)2 * n_ * Q);
   ex_v_.resize((size_t)2 * n_ * H);
@@ -1115,7 +1127,11 @@ int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
     for (auto& th : pool) th.join();
     for (int64_t d : done) games_ += d;
   }
+  const auto t4 = now();
   if (sink) sink(user, (int64_t)2 * n_, ex_lane_.data(), ex_q_.data(), Q, ex_v_.data(), H);
+  if (trace)
+    std::fprintf(stderr, "[rbl] epoch: reset %.2f ms, %d iterations %.2f ms, snapshot read-back %.2f ms, sampling walk %.2f ms, sink %.2f ms\n",
+                 ms(t0, t1), num_iters, ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
   return (int64_t)n_ * num_iters;
 }
 
