@@ -130,6 +130,41 @@ def test_batched_heterogeneous_lanes_bit_exact(d, f, iters, port):
         assert np.array_equal(v, np.stack([x for _, x in o.examples]))
 
 
+def test_full_occupancy_lanes_bit_exact(port):
+    """4096 lanes (two streams, every CU holding its full complement of CFR workgroups next to the persistent net-free
+    path): a sample of lanes, spread over both halves, still equals its own oracle run bit for bit."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    d, f, iters, B = 1, 6, 48, 4096
+    kw = dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+    A, H = port.num_actions(d, f), port.num_hands(d, f)
+    rng = np.random.default_rng(99)
+    roots = rng.integers(-1, A - 1, B)
+    roots[rng.random(B) < 0.4] = -1  # plenty of root subgames (largest trees)
+    players = rng.integers(0, 2, B)
+    beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
+    acts = rng.integers(0, iters + 1, B)
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=B)
+    e.set_net_synthetic()
+    e.reset(roots, players, beliefs, acts)
+    e.multistep()
+    for b in list(range(0, B, 173)) + [B // 2 - 1, B // 2, B - 1]:
+        o = port.solver(d, f, orc.make_params(**kw), int(roots[b]), int(players[b]), beliefs[b], orc.NET_SYNTHETIC)
+        snap = None
+        for it in range(iters):
+            if it == acts[b]:
+                snap = o.get(orc.GET_LAST)
+            o.step(it % 2)
+        if acts[b] == iters:
+            snap = o.get(orc.GET_LAST)
+        for w, ow in [(capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM), (capi.GET_REGRETS, orc.GET_REGRETS)]:
+            assert np.array_equal(e.get(b, w), o.get(ow)), (b, roots[b], w)
+        assert np.array_equal(e.get_snapshot(b), snap), (b, "snapshot", acts[b])
+        for pl in (0, 1):
+            assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
+
+
 def test_callback_net_teacher_forcing(port):
     """Leaf values supplied by the SAME host function on both sides: identical query streams, identical end state."""
     from oracle import orc
