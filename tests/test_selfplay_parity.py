@@ -62,6 +62,25 @@ def test_selfplay_many_lanes_vs_oracle(port):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
 
 
+def test_selfplay_threaded_host_walk_vs_oracle(port):
+    """1536 lanes: enough for the host-side sampling walk to be spread over several threads (engine.hip, SelfPlay::advance)
+    and for two streams; a sample of lanes still reproduces the oracle's run for its own seed, games counted correctly."""
+    from oracle import orc
+
+    c = dict(d=1, f=6, p=dict(num_iters=24, max_depth=2, linear_update=True, use_cfr=True), rap=0.25, leaf=True,
+             net="synthetic")
+    seeds = list(range(5000, 5000 + 1536))
+    games = 2
+    lanes = _run_lanes(c, seeds, games)
+    for i in list(range(0, len(seeds), 97)) + [255, 256, 767, 768, 1535]:
+        ref = port.rl_run(c["d"], c["f"], orc.make_params(**c["p"]), seeds[i], games, random_action_prob=c["rap"],
+                          sample_leaf=c["leaf"], net=orc.NET_SYNTHETIC)
+        ex = lanes[i]
+        assert len(ex) == len(ref), seeds[i]
+        for (q, v), (rq, rv) in zip(ex, ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), seeds[i]
+
+
 def test_selfplay_2d6f_global_scratch_path(port):
     """2 dice x 6 faces (H = 36, root subgame N = 325): the lane working set does not fit LDS, so the kernel runs on its
     per-lane global scratch slab; trajectories still equal the oracle's bit for bit."""
