@@ -4,7 +4,7 @@
     Oracle("ref")   -> oracle/_ref/libref_driver.so       the unmodified reference behind the same API
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; nothing under
-rebel_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+rebel_amd/ does (tests/test_capi_symbols.py::test_product_never_touches_the_oracle enforces it).
 """
 import ctypes as C
 import os

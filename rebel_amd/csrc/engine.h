@@ -105,6 +105,8 @@ class Engine {
   void write_root_query(int traverser, int last_bid, int player, const double* b0, const double* b1, float* q) const;
 
  private:
+  void construct();
+  void release_handles();
   void check_lane(int lane) const;
   void run_net();
   void launch(int mode, int trav, int next_trav, int steps_after, double alpha, double pos, double neg, double strat);
@@ -163,6 +165,7 @@ class Engine {
   bool rows_fit_ = true;  // size the row kernel's launch to the largest tree of the part
   size_t lds_bytes_ = 0, work_stride_ = 0;
   bool use_lds_ = true;
+  bool cfr_dbg_ = false;
 
   // accounting
   bool timing_ = false;

@@ -38,6 +38,16 @@ int env_int(const char* name, int dflt) {
 // =================================================================================================== Engine
 Engine::Engine(int device, int dice, int faces, const rbl_params& params, int max_lanes)
     : device_(device), g_(dice, faces), p_(params), max_lanes_(max_lanes) {
+  try {
+    construct();
+  } catch (...) {
+    release_handles();  // ~Engine does not run for a throwing constructor: no leaked streams / events / pinned memory
+    throw;
+  }
+}
+
+void Engine::construct() {
+  const int device = device_, max_lanes = max_lanes_;
   if (!p_.use_cfr && p_.dcfr) throw std::runtime_error("engine: dcfr needs use_cfr=1");
   if (p_.linear_update && p_.dcfr) throw std::runtime_error("engine: linear_update and dcfr are exclusive (subgame_solving.cc:533)");
   if (p_.max_depth < 0) throw std::runtime_error("engine: max_depth must be >= 0");
@@ -125,14 +135,17 @@ Engine::Engine(int device, int dice, int faces, const rbl_params& params, int ma
   if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
   rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
-  if (env_int("RBL_CFR_DBG", 0)) {
+  cfr_dbg_ = env_int("RBL_CFR_DBG", 0) != 0;
+  if (cfr_dbg_) {
     d_dbg_.alloc(L * 16);
     RBL_HIP_CHECK(hipMemset(d_dbg_.p, 0, L * 16 * sizeof(long long)));
   }
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-Engine::~Engine() {
+Engine::~Engine() { release_handles(); }
+
+void Engine::release_handles() {
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream2_) (void)hipStreamSynchronize(stream2_);
@@ -146,6 +159,11 @@ Engine::~Engine() {
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
+  for (int i = 0; i < 2; ++i) stream_x_[i] = nullptr;
+  ev_pool_.clear();
+  h_pinned_ = nullptr;
+  ev_ready_ = nullptr;
+  stream_ = stream2_ = nullptr;
 }
 
 void Engine::check_lane(int lane) const {
@@ -186,7 +204,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   if (w.n_out != g_.H)
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
-  const int tile = env_int("RBL_MLP_TILE", 5);  // 0 = LDS weight tape where it applies, 16 / 32 = register-streaming variants
+  const int tile = env_int("RBL_MLP_TILE", 5);  // 5 = persistent register-resident kernel, 3 = feature-split fallback
   MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be
@@ -443,19 +461,20 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.strat = strat;
   a.optimistic = p_.optimistic ? 1 : 0;
   a.br_out = d_br_.p;
-  a.dbg = d_dbg_.p && env_int("RBL_CFR_DBG", 0) ? d_dbg_.p : nullptr;
+  a.dbg = cfr_dbg_ ? d_dbg_.p : nullptr;
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int l0 = part_lane_[part], cnt = part_lane_[part + 1] - l0;
     if (cnt <= 0) continue;
     hipStream_t st = part_stream(part);
     a.lane0 = l0;
-    time_begin(0, st);
+    const bool is_step = mode == kModeStep || mode == kModeFpStep;
+    if (is_step) time_begin(0, st);
     if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
       launch_cfr(a, cnt, block_, lds_bytes_, st);
-    time_end(0, st);
+    if (is_step) time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
-    if (mode == kModeStep || mode == kModeFpStep) {
+    if (is_step) {
       if (timed_now()) {
         ++stats_.cfr_launches;
         stats_.cfr_bytes += part_bytes_[part][trav];
@@ -1150,6 +1169,14 @@ struct rbl_selfplay {
 
 namespace {
 thread_local std::string g_err;
+rbl::Engine& need(rbl_engine* e) {
+  if (!e) throw std::runtime_error("null engine handle");
+  return e->impl;
+}
+rbl::SelfPlay& need(rbl_selfplay* s) {
+  if (!s) throw std::runtime_error("null self-play handle");
+  return s->impl;
+}
 template <class F>
 int guard(F&& f) {
   try {
@@ -1212,55 +1239,55 @@ rbl_engine* rbl_engine_create(int device, int dice, int faces, const rbl_params*
   return e;
 }
 void rbl_engine_destroy(rbl_engine* e) { delete e; }
-void* rbl_engine_stream(rbl_engine* e) { return (void*)e->impl.stream(); }
+void* rbl_engine_stream(rbl_engine* e) { return e ? (void*)e->impl.stream() : nullptr; }
 
-int rbl_engine_set_net_zero(rbl_engine* e) { return guard([&] { e->impl.set_net_zero(); }); }
-int rbl_engine_set_net_synthetic(rbl_engine* e) { return guard([&] { e->impl.set_net_synthetic(); }); }
+int rbl_engine_set_net_zero(rbl_engine* e) { return guard([&] { need(e).set_net_zero(); }); }
+int rbl_engine_set_net_synthetic(rbl_engine* e) { return guard([&] { need(e).set_net_synthetic(); }); }
 int rbl_engine_set_net_mlp(rbl_engine* e, const rbl_mlp_weights* w) {
   return guard([&] {
     if (!w) throw std::runtime_error("rbl_engine_set_net_mlp: weights is null");
-    e->impl.set_net_mlp(*w);
+    need(e).set_net_mlp(*w);
   });
 }
 int rbl_engine_set_net_callback(rbl_engine* e, rbl_net_fn fn, void* user, int host_buffers) {
-  return guard([&] { e->impl.set_net_callback(fn, user, host_buffers != 0); });
+  return guard([&] { need(e).set_net_callback(fn, user, host_buffers != 0); });
 }
 int rbl_net_forward(rbl_engine* e, const float* queries, int64_t rows, float* out) {
-  return guard([&] { e->impl.net_forward_host(queries, rows, out); });
+  return guard([&] { need(e).net_forward_host(queries, rows, out); });
 }
 int rbl_net_forward_dev(rbl_engine* e, const float* queries_dev, int64_t rows, float* out_dev) {
-  return guard([&] { e->impl.net_forward_dev(queries_dev, rows, out_dev); });
+  return guard([&] { need(e).net_forward_dev(queries_dev, rows, out_dev); });
 }
 
 int rbl_solver_reset(rbl_engine* e, int B, const int32_t* root_last_bid, const int32_t* root_player,
                      const double* beliefs, const int32_t* act_iteration) {
-  return guard([&] { e->impl.reset(B, root_last_bid, root_player, beliefs, act_iteration); });
+  return guard([&] { need(e).reset(B, root_last_bid, root_player, beliefs, act_iteration); });
 }
-int rbl_solver_step(rbl_engine* e, int traverser) { return guard([&] { e->impl.step(traverser); }); }
-int rbl_solver_multistep(rbl_engine* e, int n) { return guard([&] { e->impl.multistep(n); }); }
-int rbl_solver_sync(rbl_engine* e) { return guard([&] { e->impl.sync(); }); }
-int rbl_solver_num_lanes(rbl_engine* e) { return e->impl.num_lanes(); }
+int rbl_solver_step(rbl_engine* e, int traverser) { return guard([&] { need(e).step(traverser); }); }
+int rbl_solver_multistep(rbl_engine* e, int n) { return guard([&] { need(e).multistep(n); }); }
+int rbl_solver_sync(rbl_engine* e) { return guard([&] { need(e).sync(); }); }
+int rbl_solver_num_lanes(rbl_engine* e) { return e ? e->impl.num_lanes() : -1; }
 int rbl_solver_tree_size(rbl_engine* e, int lane) {
   int n = -1;
-  guard([&] { n = e->impl.tree_size(lane); });
+  guard([&] { n = need(e).tree_size(lane); });
   return n;
 }
-int64_t rbl_solver_total_rows(rbl_engine* e) { return e->impl.total_rows(); }
+int64_t rbl_solver_total_rows(rbl_engine* e) { return e ? e->impl.total_rows() : -1; }
 int rbl_solver_get(rbl_engine* e, int lane, int which, double* out) {
-  return guard([&] { e->impl.get(lane, which, out); });
+  return guard([&] { need(e).get(lane, which, out); });
 }
 int rbl_solver_set_strategy(rbl_engine* e, int lane, const double* strategy) {
-  return guard([&] { e->impl.set_strategy(lane, strategy); });
+  return guard([&] { need(e).set_strategy(lane, strategy); });
 }
 int rbl_solver_best_response(rbl_engine* e, int traverser, double* out) {
-  return guard([&] { e->impl.best_response(traverser, out); });
+  return guard([&] { need(e).best_response(traverser, out); });
 }
 int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out) {
-  return guard([&] { rbl::strategy_recursive(e->impl, to_leaf != 0, out); });
+  return guard([&] { rbl::strategy_recursive(need(e), to_leaf != 0, out); });
 }
 
 int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, double* out) {
-  return guard([&] { rbl::strategy_recursive_sampled(e->impl, seed, root_only != 0, out); });
+  return guard([&] { rbl::strategy_recursive_sampled(need(e), seed, root_only != 0, out); });
 }
 int rbl_exploitability2(int device, int dice, int faces, const double* strategy, double out[2]) {
   return guard([&] {  // compute_exploitability2 (subgame_solving.cc:802-816): two full-tree BR sweeps, uniform beliefs
@@ -1283,7 +1310,7 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
   });
 }
 int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out) {
-  return guard([&] { e->impl.evaluate(traverser, out); });
+  return guard([&] { need(e).evaluate(traverser, out); });
 }
 int rbl_ev2(int device, int dice, int faces, const double* strategy1, const double* strategy2, double out[2]) {
   return guard([&] {  // compute_ev2 (subgame_solving.cc:975-982): player 0 follows one strategy, player 1 the other
@@ -1313,38 +1340,38 @@ int rbl_ev2(int device, int dice, int faces, const double* strategy1, const doub
   });
 }
 int rbl_solver_get_snapshot(rbl_engine* e, int lane, double* out) {
-  return guard([&] { e->impl.get_snapshot(lane, out); });
+  return guard([&] { need(e).get_snapshot(lane, out); });
 }
 int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out) {
-  return guard([&] { e->impl.hand_values(lane, player, out); });
+  return guard([&] { need(e).hand_values(lane, player, out); });
 }
 int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values) {
-  return guard([&] { e->impl.examples(lane, queries, values); });
+  return guard([&] { need(e).examples(lane, queries, values); });
 }
-int rbl_solver_get_queries(rbl_engine* e, float* out) { return guard([&] { e->impl.get_queries(out); }); }
-int rbl_solver_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { e->impl.get_debug(out); }); }
-int rbl_net_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { e->impl.get_net_debug(out); }); }
+int rbl_solver_get_queries(rbl_engine* e, float* out) { return guard([&] { need(e).get_queries(out); }); }
+int rbl_solver_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { need(e).get_debug(out); }); }
+int rbl_net_debug_stamps(rbl_engine* e, long long* out) { return guard([&] { need(e).get_net_debug(out); }); }
 
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
                                   int sample_leaf) {
   rbl_selfplay* sp = nullptr;
-  guard([&] { sp = new rbl_selfplay(&e->impl, n_lanes, seeds, random_action_prob, sample_leaf != 0); });
+  guard([&] { sp = new rbl_selfplay(&need(e), n_lanes, seeds, random_action_prob, sample_leaf != 0); });
   return sp;
 }
 void rbl_selfplay_destroy(rbl_selfplay* sp) { delete sp; }
 int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user) {
   int64_t n = -1;
-  guard([&] { n = sp->impl.advance(sink, user); });
+  guard([&] { n = need(sp).advance(sink, user); });
   return n;
 }
-int64_t rbl_selfplay_games_finished(rbl_selfplay* sp) { return sp->impl.games_finished(); }
+int64_t rbl_selfplay_games_finished(rbl_selfplay* sp) { return sp ? sp->impl.games_finished() : -1; }
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id) {
-  return guard([&] { sp->impl.state(lane, last_bid, player_id); });
+  return guard([&] { need(sp).state(lane, last_bid, player_id); });
 }
 
-int rbl_engine_timing(rbl_engine* e, int stride) { return guard([&] { e->impl.timing(stride); }); }
+int rbl_engine_timing(rbl_engine* e, int stride) { return guard([&] { need(e).timing(stride); }); }
 int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset) {
-  return guard([&] { e->impl.stats(out, reset != 0); });
+  return guard([&] { need(e).stats(out, reset != 0); });
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ namespace rbl {
 // Device-resident, MFMA-ready copy of a Net2 (cfvpy/models.py:64-94).  Built by pack_mlp() from torch-layout weights.
 struct MlpDev {
   int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
-  int tile = 0;       // kernel variant: 2 = f16x2-split LDS tape, 0 = f32 LDS tape (both n_hidden 256), 16 / 32 = f32 register streaming
+  int tile = 0;       // kernel variant: 5 = persistent register-resident (net_resident_kernel.hip), 3 = feature split
   const float* tape = nullptr;  // variant 0: the packed weights in consumption order, 32 KiB chunks
   int tape_chunks = 0, l0_chunks = 0;
   float inv_scale[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // variant 2: 1 / (power-of-two weight scale) per layer (last = output)
@@ -46,7 +46,7 @@ bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
 bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out);
 void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
 
-// out[rows][n_out] = net(queries[rows][n_in]); fp32 MFMA (v_mfma_f32_32x32x2_f32), async on `stream`.
+// out[rows][n_out] = net(queries[rows][n_in]); f16x2-split MFMA (v_mfma_f32_16x16x32_f16), async on `stream`.
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
 
 }  // namespace rbl

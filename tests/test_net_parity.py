@@ -50,12 +50,24 @@ def test_net2_vs_torch_cpu_golden():
 
 @pytest.mark.parametrize("d,f,hidden,layers_n,use_ln,rows", [
     (1, 6, 256, 2, True, 1472), (1, 6, 256, 2, True, 31), (1, 6, 256, 2, True, 33), (1, 4, 256, 2, True, 700),
-    (2, 3, 256, 2, True, 513), (2, 6, 256, 2, True, 300), (1, 6, 256, 3, True, 257), (1, 6, 128, 2, True, 200),
-    (1, 6, 64, 1, False, 100), (1, 5, 256, 2, False, 129),
+    (2, 3, 256, 2, True, 513), (2, 6, 256, 2, True, 300), (1, 6, 256, 3, True, 257), (1, 6, 256, 4, True, 200),
+    (1, 6, 256, 1, False, 100), (1, 5, 256, 2, False, 129),
     # more 64-row groups than CUs: the persistent (register-resident-weights) kernel loops, prefetching the next group
     (1, 6, 256, 2, True, 40001), (2, 3, 256, 2, True, 33000), (2, 6, 256, 2, False, 20000)])
 def test_mlp_vs_float64_reference(d, f, hidden, layers_n, use_ln, rows):
     _check_mlp(d, f, hidden, layers_n, use_ln, rows)
+
+
+def test_unsupported_net_shape_is_refused_loudly():
+    """Only n_hidden = 256 nets run on the MFMA forward; anything else raises (the rela layer then falls back to the
+    caller's TorchScript module on the GPU, never to a CPU path)."""
+    from rebel_amd import capi
+
+    e = _engine(1, 6)
+    rng = np.random.default_rng(0)
+    layers = [(rng.uniform(-1, 1, (128, e.Q)).astype(np.float32), np.zeros(128, np.float32))]
+    with pytest.raises(capi.RebelError, match="not supported"):
+        e.set_net_mlp(layers, None, rng.uniform(-1, 1, (e.H, 128)).astype(np.float32), np.zeros(e.H, np.float32))
 
 
 def test_mlp_edge_batches():
@@ -64,11 +76,10 @@ def test_mlp_edge_batches():
         _check_mlp(1, 6, 256, 2, True, rows)
 
 
-@pytest.mark.parametrize("tile", [3, 4, 2, 0])
-def test_mlp_kernel_variants(tile, monkeypatch):
-    """The older kernel variants stay selectable (RBL_MLP_TILE) and are the fallback for shapes the resident kernel does
-    not take (n_layers != 2): same tolerance."""
-    monkeypatch.setenv("RBL_MLP_TILE", str(tile))
+def test_mlp_fallback_kernel(monkeypatch):
+    """The feature-split kernel (RBL_MLP_TILE=3) is the fallback for shapes the resident kernel does not take
+    (n_layers != 2): same tolerance on the default shape too."""
+    monkeypatch.setenv("RBL_MLP_TILE", "3")
     _check_mlp(1, 6, 256, 2, True, 5000)
 
 
