@@ -146,6 +146,7 @@ void Engine::construct() {
 Engine::~Engine() { release_handles(); }
 
 void Engine::release_handles() {
+  if (!stream_ && !stream2_ && !stream_x_[0] && !stream_x_[1] && !ev_ready_ && !h_pinned_ && ev_pool_.empty()) return;
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream2_) (void)hipStreamSynchronize(stream2_);
