@@ -138,8 +138,22 @@ rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* see
 void rbl_selfplay_destroy(rbl_selfplay* sp);
 /* Advances every lane by ONE subgame (num_iters CFR steps + sampling, recursive_solving.cc:166-181) and hands the
  * 2*n_lanes training examples to `sink` in lane order.  Returns the number of subgame-CFR-iterations executed
- * (n_lanes * num_iters) or -1 on error. */
+ * (n_lanes * num_iters) or -1 on error.
+ * The whole epoch -- RlRunner::step's draws (act_iteration :168-169), the sampling walk (sample_state_to_leaf :192-246 /
+ * sample_state_single :248-275), the Bayes updates (:41-44) and the example encoding (subgame_solving.cc:672-676) -- runs
+ * as HIP kernels between the CFR launches (selfplay_kernels.hip); the host only receives the examples.  With a callback
+ * net (rbl_engine_set_net_callback) or RBL_SELFPLAY_HOST=1 the walk runs on the host instead: same trajectories. */
 int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user);
+/* 1 if the lanes' walk runs on the device (decided at the first advance), 0 on the host, -1 before the first advance */
+int rbl_selfplay_on_device(rbl_selfplay* sp);
+/* Device pointers to the LAST epoch's examples, queries [2*n_lanes][Q] and values [2*n_lanes][H] f32, valid until the next
+ * advance (replaces per-example tensor allocation, subgame_solving.cc:220-226, for a device-resident replay buffer);
+ * both null when the walk runs on the host. */
+int rbl_selfplay_device_examples(rbl_selfplay* sp, const float** queries_dev, const float** values_dev);
+/* Self-test of the device restatement of libstdc++'s <random> (std::mt19937(seed) driving uniform_int_distribution<int>(0,
+ * hi), uniform_real_distribution<float>(0,1), discrete_distribution<int>(w, w + nw)): out[3 * rounds] = the draws, in that
+ * order per round, produced by the GPU.  tests/ compares them with the host library draw for draw. */
+int rbl_selftest_device_rng(int device, int32_t seed, int rounds, int hi, const double* w, int nw, double* out);
 int64_t rbl_selfplay_games_finished(rbl_selfplay* sp);
 /* per-lane public state for inspection: last_bid, player_id (liars_dice.h:35-44) */
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id);

@@ -900,5 +900,17 @@ void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float*
                        int num_actions) {
   synthetic_net(queries, rows, qsize, out, osize, num_actions);
 }
+// The reference's random draws come from libstdc++ <random> driven by std::mt19937 (recursive_solving.cc:168-169, 198-215):
+// per round uniform_int_distribution<int>(0, hi), uniform_real_distribution<float>(0, 1), discrete_distribution<int>(w).
+// The device restatement (rebel_amd/csrc/selfplay_kernels.hip) is checked against this draw for draw.
+void orc_rng_probe(int seed, int rounds, int hi, const double* w, int nw, double* out) {
+  std::mt19937 gen(seed);
+  for (int k = 0; k < rounds; ++k) {
+    out[3 * k + 0] = (double)std::uniform_int_distribution<>(0, hi)(gen);
+    out[3 * k + 1] = (double)std::uniform_real_distribution<float>(0, 1)(gen);
+    std::discrete_distribution<int> d(w, w + nw);
+    out[3 * k + 2] = (double)d(gen);
+  }
+}
 
 }  // extern "C"

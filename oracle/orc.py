@@ -105,6 +105,16 @@ class Oracle:
         L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                                         C.c_int]
         L.orc_synthetic_net.restype = None
+        L.orc_rng_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        L.orc_rng_probe.restype = None
+
+    def rng_probe(self, seed, rounds, hi, weights):
+        """libstdc++ draws from std::mt19937(seed): float64[rounds, 3] = uniform_int(0, hi), uniform_real<float>, discrete."""
+        w = np.ascontiguousarray(weights, np.float64)
+        out = np.zeros((rounds, 3))
+        self.lib.orc_rng_probe(seed, rounds, hi, w.ctypes.data_as(C.POINTER(C.c_double)), len(w),
+                               out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     # ---- game rules
     def impl_name(self):

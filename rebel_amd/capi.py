@@ -28,7 +28,8 @@ SYMBOLS = [
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
     "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
-    "rbl_selfplay_state", "rbl_engine_timing", "rbl_engine_stats",
+    "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
+    "rbl_engine_timing", "rbl_engine_stats",
 ]
 
 
@@ -124,6 +125,9 @@ def lib():
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
         "rbl_selfplay_games_finished": (C.c_int64, [vp]),
         "rbl_selfplay_state": (C.c_int, [vp, C.c_int, i32p, i32p]),
+        "rbl_selfplay_on_device": (C.c_int, [vp]),
+        "rbl_selfplay_device_examples": (C.c_int, [vp, C.POINTER(fp), C.POINTER(fp)]),
+        "rbl_selftest_device_rng": (C.c_int, [C.c_int, C.c_int32, C.c_int, C.c_int, dp, C.c_int, dp]),
         "rbl_engine_timing": (C.c_int, [vp, C.c_int]),
         "rbl_engine_stats": (C.c_int, [vp, C.POINTER(KernelStats), C.c_int]),
     }
@@ -359,6 +363,15 @@ class Engine:
         return {k: getattr(s, k) for k, _ in KernelStats._fields_}
 
 
+def device_rng_draws(seed, rounds, hi, weights, device=0):
+    """The GPU's restatement of libstdc++ <random> (selfplay_kernels.hip): per round uniform_int(0, hi), canonical float,
+    discrete(weights) from mt19937(seed) -> float64[rounds, 3]."""
+    w = np.ascontiguousarray(weights, np.float64)
+    out = np.zeros((rounds, 3))
+    _check(lib().rbl_selftest_device_rng(device, seed, rounds, hi, _p(w, C.c_double), len(w), _p(out, C.c_double)))
+    return out
+
+
 class SelfPlay:
     """RlRunner lanes (recursive_solving.h:40-86) on an Engine; advance() = one subgame per lane."""
 
@@ -388,6 +401,10 @@ class SelfPlay:
 
     def games_finished(self):
         return self.e.L.rbl_selfplay_games_finished(self.h)
+
+    def on_device(self):
+        """1: the sampling walk runs as HIP kernels; 0: on the host (callback net / RBL_SELFPLAY_HOST=1); -1: undecided."""
+        return self.e.L.rbl_selfplay_on_device(self.h)
 
     def state(self, lane):
         a, b = C.c_int32(), C.c_int32()

@@ -72,7 +72,8 @@ inline size_t cfr_work_reals(int N, int H, int L, int T, int dice, int faces) {
 }
 
 // test double of the value net (oracle/orc_api.h: orc_synthetic_net); lives in the -ffp-contract=off TU
-void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream);
+void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream,
+                          const long long* range = nullptr);
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
 

@@ -475,7 +475,12 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
 // Test double of the value net (oracle/orc_api.h: orc_synthetic_net), elementwise, exact in IEEE float:
 //   v[h] = ((0.5f*q[2+A+h] - 0.25f*q[2+A+H+h]) + 0.125f*(q[1]-q[0])) + 0.0625f*q[2 + h % A]
 __global__ void synthetic_net_kernel(const float* __restrict__ queries, int64_t rows, int Q, float* __restrict__ out,
-                                     int H, int A) {
+                                     int H, int A, const long long* __restrict__ range) {
+  if (range) {  // device-side row range (see launch_mlp_forward)
+    queries += range[0] * Q;
+    out += range[0] * H;
+    rows = range[1] - range[0];
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * H) return;
   const int64_t r = i / H;
@@ -490,11 +495,12 @@ __global__ void synthetic_net_kernel(const float* __restrict__ queries, int64_t 
 
 }  // namespace
 
-void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream) {
+void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream,
+                          const long long* range) {
   if (rows <= 0) return;
   const int64_t n = rows * H;
   hipLaunchKernelGGL(synthetic_net_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, queries, rows, Q,
-                     out, H, A);
+                     out, H, A, range);
 }
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream) {

@@ -17,6 +17,7 @@
 #include "../../include/rebel_hip.h"
 #include "cfr_kernels.h"
 #include "net_kernels.h"
+#include "selfplay_kernels.h"
 #include "tables.h"
 
 namespace rbl {
@@ -66,7 +67,8 @@ class Engine {
   void set_net_synthetic();
   void set_net_mlp(const rbl_mlp_weights& w);
   void set_net_callback(rbl_net_fn fn, void* user, bool host_buffers);
-  void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st = nullptr);  // async
+  void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st = nullptr,
+                       const long long* range = nullptr);  // async; `range`: see launch_mlp_forward
   void net_forward_host(const float* q, int64_t rows, float* out);
 
   // ---- batched solver
@@ -76,7 +78,7 @@ class Engine {
   void multistep(int n);
   void sync();
   int num_lanes() const { return B_; }
-  int tree_size(int lane) const;
+  int tree_size(int lane);
   int64_t total_rows() const { return rows_; }
   void get(int lane, int which, double* out);
   void get_snapshot(int lane, double* out);
@@ -88,6 +90,30 @@ class Engine {
   void get_queries(float* out);
   void get_debug(long long* out);
   void get_net_debug(long long* out);  // RBL_NET_DBG=1: phase stamps of the last net forward (first 1024 workgroups)  // RBL_CFR_DBG=1: per-lane phase timestamps of the last CFR launch
+
+  // ---- device-resident epochs (SelfPlay): lane descriptors, row offsets and part boundaries are produced by kernels
+  // (selfplay_kernels.hip) on stream(); the host never learns an epoch's row counts before its end
+  struct DeviceLanes {
+    int *shape, *player, *row, *act;
+    double* beliefs;
+    const double *snapshot, *root_mean;
+    const int* shape_epar;
+  };
+  DeviceLanes device_lanes() const {
+    return DeviceLanes{d_lane_shape_.p, d_lane_player_.p, d_lane_row_.p, d_lane_act_.p, d_beliefs_.p, d_snapshot_.p,
+                       d_root_mean_.p, d_shape_epar_.p};
+  }
+  const ShapeDev* shapes_dev() const { return d_shapes_.p; }
+  const int* act_dev() const { return d_act_.p; }
+  const int* cb_dev() const { return d_cb_.p; }
+  const int* ce_dev() const { return d_ce_.p; }
+  const int* depth_dev() const { return d_depth_.p; }
+  bool device_epochs_supported() const { return net_mode_ != NetMode::kCallback; }
+  int parts_for(int B) const;                                    // lane parts (= streams) a batch of B lanes is split into
+  void part_lanes(int B, int* part_lane /*[kSpMaxParts+1]*/) const;
+  void begin_epoch_device(int B, const SpEpochInfo* info_dev);   // descriptors already enqueued on stream(); solver init
+  void join_streams();                                           // stream() waits for the other parts' streams
+  void end_epoch_device(const SpEpochInfo& info);                // accounting of the timed launches; rows of the epoch
 
   // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
   void read_snapshots(const double** snap, const double** root_mean);  // pinned host copies, valid until the next call
@@ -106,6 +132,7 @@ class Engine {
 
  private:
   void construct();
+  void ensure_mirror();  // device-resident epochs: refresh the host copies of the lane descriptors on demand
   void release_handles();
   void check_lane(int lane) const;
   void run_net();
@@ -123,6 +150,10 @@ class Engine {
   int max_lanes_, emax_, nmax_;
   hipStream_t stream_ = nullptr, stream2_ = nullptr;
   hipEvent_t ev_ready_ = nullptr;
+  hipEvent_t ev_join_[3] = {nullptr, nullptr, nullptr};
+  const SpEpochInfo* info_dev_ = nullptr;  // non-null: device-resident epoch (row ranges live on the device)
+  bool mirror_valid_ = true;
+  long long timed_cfr_[4][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, timed_net_[4] = {0, 0, 0, 0};
   hipStream_t stream_x_[2] = {nullptr, nullptr};
   int n_parts_ = 1, max_parts_ = 2, only_part_ = -1, split_min_lanes_ = 1024;
   int part_lane_[5] = {0, 0, 0, 0, 0};
@@ -133,6 +164,7 @@ class Engine {
   DevBuf<ShapeDev> d_shapes_;
   DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_;
   DevBuf<int8_t> d_matches_;
+  DevBuf<int> d_shape_epar_;
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;
   DevBuf<long long> d_dbg_, d_ndbg_;
@@ -185,7 +217,14 @@ class Engine {
 class SelfPlay {
  public:
   SelfPlay(Engine* e, int n_lanes, const int32_t* seeds, double random_action_prob, bool sample_leaf);
+  ~SelfPlay();
+  SelfPlay(const SelfPlay&) = delete;
+  SelfPlay& operator=(const SelfPlay&) = delete;
   int64_t advance(rbl_example_fn sink, void* user);
+  int mode() const { return mode_; }
+  bool on_device() const { return mode_ == 1; }  // the walk runs as kernels (selfplay_kernels.hip), decided at the first advance()
+  // the last epoch's examples as device pointers ([2n][Q], [2n][H]), valid until the next advance(); null in host mode
+  void device_examples(const float** q, const float** v) const;
   int64_t games_finished() const { return games_; }
   void state(int lane, int32_t* last_bid, int32_t* player) const;
   int num_lanes() const { return n_; }
@@ -195,10 +234,24 @@ class SelfPlay {
   void sample_single(int lane, const double* sigma);
   void bayes(double* b, const double* sigma, int shape_node_off, int child, int H) const;
 
+  int64_t advance_host(rbl_example_fn sink, void* user);
+  int64_t advance_device(rbl_example_fn sink, void* user);
+  void init_device();
+  SpArgs sp_args() const;
+
   Engine* e_;
   int n_;
   float rap_;
   bool leaf_;
+  int mode_ = -1;  // -1 undecided, 0 host walk (callback nets, RBL_SELFPLAY_HOST=1), 1 device walk
+  std::vector<int32_t> seeds_;
+  // device walk: RNG, game state and the epoch's examples live on the GPU; the host sees examples + (bid, player)
+  DevBuf<uint32_t> d_mt_;
+  DevBuf<int> d_mt_idx_, d_bid_, d_player_;
+  DevBuf<double> d_sp_beliefs_;
+  DevBuf<float> d_ex_q_, d_ex_v_;
+  DevBuf<SpEpochInfo> d_info_;
+  unsigned char* h_pin_ = nullptr;  // pinned: ex_q, ex_v, bid, player, info
   std::vector<std::mt19937> gen_;
   std::vector<int32_t> bid_, player_, act_;
   std::vector<double> beliefs_;  // [n][2][H]

@@ -61,6 +61,7 @@ void Engine::construct() {
   for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_x_[i], hipStreamNonBlocking));
   max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", 2)));
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
+  for (int i = 0; i < 3; ++i) RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
   split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
 
   {  // full trees grow as 2^A: refuse what cannot be tabulated (2 dice x 6 faces full tree = 33.5 M nodes per shape)
@@ -95,6 +96,12 @@ void Engine::construct() {
   for (int f = 0; f < g_.faces; ++f)
     for (int h = 0; h < g_.H; ++h) m[(size_t)f * g_.H + h] = (int8_t)g_.matches(h, f);
   d_matches_.upload(m, stream_);
+  std::vector<int> epar(2 * tabs_.shapes.size(), 0);  // edges by the depth parity of their parent (roofline accounting)
+  for (size_t si = 0; si < tabs_.shapes.size(); ++si) {
+    const ShapeDev& s = tabs_.shapes[si];
+    for (int n = 1; n < s.N; ++n) ++epar[2 * si + (tabs_.depth[s.node_off + tabs_.parent[s.node_off + n]] & 1)];
+  }
+  d_shape_epar_.upload(epar, stream_);
 
   const size_t L = (size_t)max_lanes_;
   const size_t eh = (size_t)emax_ * g_.H;
@@ -146,7 +153,9 @@ void Engine::construct() {
 Engine::~Engine() { release_handles(); }
 
 void Engine::release_handles() {
-  if (!stream_ && !stream2_ && !stream_x_[0] && !stream_x_[1] && !ev_ready_ && !h_pinned_ && ev_pool_.empty()) return;
+  if (!stream_ && !stream2_ && !stream_x_[0] && !stream_x_[1] && !ev_ready_ && !h_pinned_ && ev_pool_.empty() &&
+      !ev_join_[0])
+    return;
   (void)hipSetDevice(device_);
   if (stream_) (void)hipStreamSynchronize(stream_);
   if (stream2_) (void)hipStreamSynchronize(stream2_);
@@ -158,6 +167,10 @@ void Engine::release_handles() {
   for (auto e : ev_pool_) (void)hipEventDestroy(e);
   if (h_pinned_) (void)hipHostFree(h_pinned_);
   if (ev_ready_) (void)hipEventDestroy(ev_ready_);
+  for (int i = 0; i < 3; ++i) {
+    if (ev_join_[i]) (void)hipEventDestroy(ev_join_[i]);
+    ev_join_[i] = nullptr;
+  }
   if (stream_) (void)hipStreamDestroy(stream_);
   if (stream2_) (void)hipStreamDestroy(stream2_);
   for (int i = 0; i < 2; ++i) stream_x_[i] = nullptr;
@@ -244,19 +257,21 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   values_zeroed_ = false;
 }
 
-void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st) {
+void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st, const long long* range) {
   if (rows <= 0) return;
+  if (range && net_mode_ == NetMode::kCallback)
+    throw std::runtime_error("net: a callback net needs host-side row counts (device-resident epochs are not available)");
   if (!st) st = stream_;
   const int Q = g_.query_size(), H = g_.H;
   switch (net_mode_) {
     case NetMode::kZero:
-      RBL_HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)rows * H * sizeof(float), st));
+      if (!range) RBL_HIP_CHECK(hipMemsetAsync(out_dev, 0, (size_t)rows * H * sizeof(float), st));
       break;
     case NetMode::kSynthetic:
-      launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, st);
+      launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, st, range);
       break;
     case NetMode::kMlp:
-      launch_mlp_forward(mlp_, q_dev, rows, out_dev, st);
+      launch_mlp_forward(mlp_, q_dev, rows, out_dev, st, range);
       break;
     case NetMode::kCallback:
       if (cb_host_) {
@@ -365,6 +380,8 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
     }
   }
   has_act_ = act_iteration != nullptr;
+  info_dev_ = nullptr;
+  mirror_valid_ = true;
   B_ = B;
   rows_ = rows;
   iter_ = 0;
@@ -376,12 +393,9 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_beliefs_.upload(h_beliefs_, stream_);
   // two half-batches on two streams: one half's CFR step overlaps the other half's value-net forward (the two
   // kernels stress different units); halves are independent lane sets, rows of a half are contiguous
-  n_parts_ = 1;
-  while (n_parts_ < max_parts_ && B >= (n_parts_ + 1) * split_min_lanes_) ++n_parts_;
-  for (int pt = 0; pt <= n_parts_; ++pt) {
-    part_lane_[pt] = (int)((int64_t)B * pt / n_parts_);
-    part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
-  }
+  n_parts_ = parts_for(B);
+  part_lanes(B, part_lane_);
+  for (int pt = 0; pt <= n_parts_; ++pt) part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
   for (int pt = 0; pt < 4; ++pt) {
     part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
     part_rows_lds_[pt] = 0;
@@ -414,6 +428,103 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   num_strategies_ = 0;
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
+}
+
+int Engine::parts_for(int B) const {
+  int n = 1;
+  while (n < max_parts_ && B >= (n + 1) * split_min_lanes_) ++n;
+  return n;
+}
+
+void Engine::part_lanes(int B, int* part_lane) const {
+  const int n = parts_for(B);
+  for (int pt = 0; pt <= kSpMaxParts; ++pt) part_lane[pt] = pt <= n ? (int)((int64_t)B * pt / n) : B;
+}
+
+// Device-resident epoch: the lane descriptors (shape, root player, first net row, act_iteration, root beliefs) and the
+// parts' row boundaries were written by sp_begin / sp_scan, already enqueued on stream_.  Nothing is known on the host
+// but the lane count, so launches take the largest shape's configuration and the net kernels read their row range from
+// `info_dev`.  No host synchronisation: the previous epoch's kernels are ordered before this one by stream_.
+void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  if (B < 1 || B > max_lanes_) throw std::runtime_error("begin_epoch_device: B must be in [1, max_lanes]");
+  if (!device_epochs_supported())
+    throw std::runtime_error("begin_epoch_device: a callback net needs host-side row counts");
+  info_dev_ = info_dev;
+  mirror_valid_ = false;
+  has_act_ = true;
+  B_ = B;
+  rows_ = (int64_t)B * tabs_.max_L;  // upper bound until end_epoch_device
+  iter_ = 0;
+  num_steps_[0] = num_steps_[1] = 0;
+  num_strategies_ = 0;
+  n_parts_ = parts_for(B);
+  part_lanes(B, part_lane_);
+  for (int pt = 0; pt < 4; ++pt) {
+    part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
+    part_rows_lds_[pt] = rows_lds_bytes_;
+    part_rows_block_[pt] = rows_block_;
+  }
+  for (int pt = 0; pt <= n_parts_; ++pt) part_row_[pt] = (int64_t)part_lane_[pt] * tabs_.max_L;  // bounds only
+  RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
+  for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
+  launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
+  pending_trav_ = 0;
+}
+
+void Engine::join_streams() {
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  for (int pt = 1; pt < n_parts_; ++pt) {
+    RBL_HIP_CHECK(hipEventRecord(ev_join_[pt - 1], part_stream(pt)));
+    RBL_HIP_CHECK(hipStreamWaitEvent(stream_, ev_join_[pt - 1], 0));
+  }
+}
+
+void Engine::end_epoch_device(const SpEpochInfo& info) {
+  rows_ = info.rows;
+  const double per_row = net_mode_ == NetMode::kMlp
+                             ? 2.0 * ((double)mlp_.n_in * mlp_.n_hidden +
+                                      (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
+                                      (double)mlp_.n_hidden * mlp_.n_out)
+                             : 0.0;
+  for (int pt = 0; pt < n_parts_; ++pt) {
+    part_row_[pt] = info.part_row[pt];
+    for (int t = 0; t < 2; ++t) {
+      part_bytes_[pt][t] = (double)info.part_bytes[pt][t];
+      stats_.cfr_bytes += (double)timed_cfr_[pt][t] * part_bytes_[pt][t];
+      timed_cfr_[pt][t] = 0;
+    }
+    const double nr = (double)(info.part_row[pt + 1] - info.part_row[pt]);
+    stats_.net_rows += (int64_t)(timed_net_[pt] * nr);
+    stats_.net_flops += timed_net_[pt] * nr * per_row;
+    timed_net_[pt] = 0;
+  }
+  part_row_[n_parts_] = info.rows;
+}
+
+void Engine::ensure_mirror() {
+  if (mirror_valid_) return;
+  sync();
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  const int H = g_.H;
+  h_shape_.resize(B_);
+  h_player_.resize(B_);
+  h_row_.resize(B_);
+  h_act_.resize(B_);
+  h_bid_.resize(B_);
+  h_beliefs_.resize((size_t)B_ * 2 * H);
+  RBL_HIP_CHECK(hipMemcpy(h_shape_.data(), d_lane_shape_.p, B_ * sizeof(int), hipMemcpyDeviceToHost));
+  RBL_HIP_CHECK(hipMemcpy(h_player_.data(), d_lane_player_.p, B_ * sizeof(int), hipMemcpyDeviceToHost));
+  RBL_HIP_CHECK(hipMemcpy(h_row_.data(), d_lane_row_.p, B_ * sizeof(int), hipMemcpyDeviceToHost));
+  RBL_HIP_CHECK(hipMemcpy(h_act_.data(), d_lane_act_.p, B_ * sizeof(int), hipMemcpyDeviceToHost));
+  RBL_HIP_CHECK(hipMemcpy(h_beliefs_.data(), d_beliefs_.p, (size_t)B_ * 2 * H * sizeof(double), hipMemcpyDeviceToHost));
+  int64_t rows = 0;
+  for (int b = 0; b < B_; ++b) {
+    h_bid_[b] = h_shape_[b] - 1;
+    rows += tabs_.shapes[h_shape_[b]].L;
+  }
+  rows_ = rows;
+  mirror_valid_ = true;
 }
 
 void Engine::launch(int mode, int trav, int next_trav, int steps_after, double alpha, double pos, double neg,
@@ -478,7 +589,10 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     if (is_step) {
       if (timed_now()) {
         ++stats_.cfr_launches;
-        stats_.cfr_bytes += part_bytes_[part][trav];
+        if (info_dev_)
+          ++timed_cfr_[part][trav];  // bytes are added at the end of the epoch (end_epoch_device)
+        else
+          stats_.cfr_bytes += part_bytes_[part][trav];
       }
       stats_.lane_steps += cnt;
     }
@@ -486,7 +600,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
 }
 
 void Engine::run_net() {
-  if (rows_ == 0) return;
+  if (rows_ == 0 || tabs_.max_L == 0) return;
   std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (net_mode_ == NetMode::kZero) {
     if (!values_zeroed_) {
@@ -505,6 +619,15 @@ void Engine::run_net() {
     hipStream_t st = part_stream(part);
     const bool timed = net_mode_ == NetMode::kMlp && timed_now();
     if (timed) time_begin(1, st);
+    if (info_dev_) {  // rows [part_row[part], part_row[part + 1]) as written by sp_scan; nr is only the launch bound
+      net_forward_dev(d_queries_.p, nr, d_values_.p, st, info_dev_->part_row + part);
+      if (timed) {
+        time_end(1, st);
+        ++stats_.net_launches;
+        ++timed_net_[part];
+      }
+      continue;
+    }
     net_forward_dev(d_queries_.p + r0 * Q, nr, d_values_.p + r0 * H, st);
     if (timed) {
       time_end(1, st);
@@ -578,7 +701,8 @@ void Engine::sync() {
   for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamSynchronize(stream_x_[i]));
 }
 
-int Engine::tree_size(int lane) const {
+int Engine::tree_size(int lane) {
+  ensure_mirror();
   check_lane(lane);
   return tabs_.shapes[h_shape_[lane]].N;
 }
@@ -605,6 +729,7 @@ void Engine::expand_dense(int lane, const std::vector<double>& edge, double* out
 }
 
 void Engine::get(int lane, int which, double* out) {
+  ensure_mirror();
   check_lane(lane);
   std::vector<double> edge;
   const ShapeDev& s = tabs_.shapes[h_shape_[lane]];
@@ -657,6 +782,7 @@ void Engine::get(int lane, int which, double* out) {
 
 // dense [N][H][A] -> the lane's edge-indexed sigma (for best-response / exploitability evaluation of a given strategy)
 void Engine::set_strategy(int lane, const double* dense) {
+  ensure_mirror();
   check_lane(lane);
   sync();
   const ShapeDev& s = tabs_.shapes[h_shape_[lane]];
@@ -674,6 +800,7 @@ void Engine::set_strategy(int lane, const double* dense) {
 
 // BRSolver::compute_br (subgame_solving.cc:316-358) for every lane against its current sigma; out [B][H] root values
 void Engine::best_response(int traverser, double* out) {
+  ensure_mirror();
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (B_ == 0) throw std::runtime_error("best_response: no lanes (call reset first)");
   if (traverser != 0 && traverser != 1) throw std::runtime_error("best_response: traverser must be 0 or 1");
@@ -692,6 +819,7 @@ void Engine::best_response(int traverser, double* out) {
 // opponent's reach is taken under the same sigma (set_strategy a mix of the two strategies to evaluate one against the
 // other); pseudo-leaves of depth-limited trees are valued by the engine's net like in best_response.
 void Engine::evaluate(int traverser, double* out) {
+  ensure_mirror();
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (B_ == 0) throw std::runtime_error("evaluate: no lanes (call reset first)");
   if (traverser != 0 && traverser != 1) throw std::runtime_error("evaluate: traverser must be 0 or 1");
@@ -707,6 +835,7 @@ void Engine::evaluate(int traverser, double* out) {
 }
 
 void Engine::get_snapshot(int lane, double* out) {
+  ensure_mirror();
   check_lane(lane);
   if (!has_act_) throw std::runtime_error("get_snapshot: reset was called without act_iteration");
   if (iter_ < h_act_[lane]) throw std::runtime_error("get_snapshot: lane has not reached its act_iteration yet");
@@ -716,6 +845,7 @@ void Engine::get_snapshot(int lane, double* out) {
 }
 
 void Engine::hand_values(int lane, int player, double* out) {
+  ensure_mirror();
   sync();
   check_lane(lane);
   if (player != 0 && player != 1) throw std::runtime_error("hand_values: player must be 0 or 1");
@@ -737,6 +867,7 @@ void Engine::write_root_query(int traverser, int last_bid, int player, const dou
 }
 
 void Engine::examples(int lane, float* queries, float* values) {
+  ensure_mirror();
   sync();  // update_value_network, subgame_solving.cc:672-676
   check_lane(lane);
   const int H = g_.H, Q = g_.query_size();
@@ -765,6 +896,7 @@ void Engine::get_debug(long long* out) {
 }
 
 void Engine::get_queries(float* out) {
+  ensure_mirror();
   sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
   if (rows_ > 0)
@@ -988,6 +1120,7 @@ SelfPlay::SelfPlay(Engine* e, int n_lanes, const int32_t* seeds, double random_a
     : e_(e), n_(n_lanes), rap_((float)random_action_prob), leaf_(sample_leaf) {
   if (n_lanes < 1 || n_lanes > e->max_lanes()) throw std::runtime_error("selfplay: n_lanes must be in [1, max_lanes]");
   const Rules& g = e->rules();
+  seeds_.assign(seeds, seeds + n_);
   for (int i = 0; i < n_; ++i) gen_.emplace_back(seeds[i]);  // RlRunner: std::mt19937 gen_(seed)
   bid_.assign(n_, g.liar);  // "terminal": the first advance() starts a fresh game on every lane
   player_.assign(n_, 0);
@@ -1083,7 +1216,138 @@ void SelfPlay::sample_single(int lane, const double* sigma) {  // recursive_solv
   player_[lane] = 1 - pl;
 }
 
+SelfPlay::~SelfPlay() {
+  if (h_pin_) (void)hipHostFree(h_pin_);
+}
+
+void SelfPlay::device_examples(const float** q, const float** v) const {
+  *q = mode_ == 1 ? d_ex_q_.p : nullptr;
+  *v = mode_ == 1 ? d_ex_v_.p : nullptr;
+}
+
+// The walk runs on the device unless the value net is a host/device callback (the net launch then needs host-side row
+// counts every iteration) or RBL_SELFPLAY_HOST=1 asks for the host walk (A/B: both produce identical trajectories,
+// tests/test_selfplay_parity.py).  Decided once, at the first epoch: the two modes keep separate RNG states.
 int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
+  if (mode_ < 0) {
+    const Rules& g = e_->rules();
+    const bool ok = e_->device_epochs_supported() && !env_int("RBL_SELFPLAY_HOST", 0) && g.H <= 64 && g.A <= 64 &&
+                    (leaf_ || e_->params().max_depth >= 1);
+    mode_ = ok ? 1 : 0;
+    if (mode_ == 1) init_device();
+  }
+  if (mode_ == 1) {
+    if (!e_->device_epochs_supported())
+      throw std::runtime_error("selfplay: the value net became a callback net after device self-play started; create "
+                               "the lanes after setting the net, or run with RBL_SELFPLAY_HOST=1");
+    return advance_device(sink, user);
+  }
+  return advance_host(sink, user);
+}
+
+void SelfPlay::init_device() {
+  const Rules& g = e_->rules();
+  const int H = g.H, Q = g.query_size();
+  RBL_HIP_CHECK(hipSetDevice(e_->device()));
+  hipStream_t st = e_->stream();
+  std::vector<uint32_t> mt((size_t)624 * n_), one(624);
+  for (int i = 0; i < n_; ++i) {
+    mt19937_seed_state((uint32_t)seeds_[i], one.data());  // std::mt19937(seed): seed taken modulo 2^32
+    for (int k = 0; k < 624; ++k) mt[(size_t)k * n_ + i] = one[k];
+  }
+  d_mt_.upload(mt, st);
+  d_mt_idx_.upload(std::vector<int>(n_, 624), st);
+  d_bid_.upload(std::vector<int>(bid_.begin(), bid_.end()), st);
+  d_player_.upload(std::vector<int>(player_.begin(), player_.end()), st);
+  d_sp_beliefs_.upload(beliefs_, st);
+  d_ex_q_.alloc((size_t)2 * n_ * Q);
+  d_ex_v_.alloc((size_t)2 * n_ * H);
+  d_info_.alloc(1);
+  RBL_HIP_CHECK(hipMemsetAsync(d_info_.p, 0, sizeof(SpEpochInfo), st));
+  const size_t bytes = (size_t)2 * n_ * (Q + H) * sizeof(float) + (size_t)2 * n_ * sizeof(int) + sizeof(SpEpochInfo);
+  RBL_HIP_CHECK(hipHostMalloc((void**)&h_pin_, bytes, hipHostMallocDefault));
+  RBL_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above go out of scope
+  ex_lane_.resize((size_t)2 * n_);
+  for (int i = 0; i < n_; ++i) ex_lane_[2 * i] = ex_lane_[2 * i + 1] = i;
+}
+
+SpArgs SelfPlay::sp_args() const {
+  const Rules& g = e_->rules();
+  const Engine::DeviceLanes dl = e_->device_lanes();
+  SpArgs a{};
+  a.shapes = e_->shapes_dev();
+  a.act = e_->act_dev();
+  a.cb = e_->cb_dev();
+  a.ce = e_->ce_dev();
+  a.depth = e_->depth_dev();
+  a.shape_epar = dl.shape_epar;
+  a.H = g.H;
+  a.A = g.A;
+  a.Q = g.query_size();
+  a.liar = g.liar;
+  a.Emax = e_->emax();
+  a.num_iters = e_->params().num_iters;
+  a.n = n_;
+  a.sample_leaf = leaf_ ? 1 : 0;
+  a.rap = rap_;
+  a.mt = d_mt_.p;
+  a.mt_idx = d_mt_idx_.p;
+  a.bid = d_bid_.p;
+  a.player = d_player_.p;
+  a.beliefs = d_sp_beliefs_.p;
+  a.lane_shape = dl.shape;
+  a.lane_player = dl.player;
+  a.lane_row = dl.row;
+  a.lane_act = dl.act;
+  a.eng_beliefs = dl.beliefs;
+  a.snapshot = dl.snapshot;
+  a.root_mean = dl.root_mean;
+  a.ex_q = d_ex_q_.p;
+  a.ex_v = d_ex_v_.p;
+  a.info = d_info_.p;
+  a.n_parts = e_->parts_for(n_);
+  e_->part_lanes(n_, a.part_lane);
+  return a;
+}
+
+// One epoch without the host in the loop: [sp_begin, sp_scan] -> solver init -> num_iters x (net, CFR step) on the
+// engine's streams -> [sp_end]; the only read-back is the epoch's examples (2n x (Q + H) floats) and 8 bytes of game
+// state per lane, after which the next epoch's launches follow immediately.
+int64_t SelfPlay::advance_device(rbl_example_fn sink, void* user) {
+  const Rules& g = e_->rules();
+  const int H = g.H, Q = g.query_size();
+  const int num_iters = e_->params().num_iters;
+  RBL_HIP_CHECK(hipSetDevice(e_->device()));
+  hipStream_t st = e_->stream();
+  const SpArgs a = sp_args();
+  launch_sp_begin(a, st);
+  launch_sp_scan(a, st);
+  RBL_HIP_CHECK(hipGetLastError());
+  e_->begin_epoch_device(n_, d_info_.p);
+  e_->multistep(num_iters);
+  e_->join_streams();
+  launch_sp_end(a, st);
+  RBL_HIP_CHECK(hipGetLastError());
+  float* hq = reinterpret_cast<float*>(h_pin_);
+  float* hv = hq + (size_t)2 * n_ * Q;
+  int* hb = reinterpret_cast<int*>(hv + (size_t)2 * n_ * H);
+  int* hp = hb + n_;
+  SpEpochInfo* hi = reinterpret_cast<SpEpochInfo*>(hp + n_);
+  RBL_HIP_CHECK(hipMemcpyAsync(hq, d_ex_q_.p, (size_t)2 * n_ * Q * sizeof(float), hipMemcpyDeviceToHost, st));
+  RBL_HIP_CHECK(hipMemcpyAsync(hv, d_ex_v_.p, (size_t)2 * n_ * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  RBL_HIP_CHECK(hipMemcpyAsync(hb, d_bid_.p, (size_t)n_ * sizeof(int), hipMemcpyDeviceToHost, st));
+  RBL_HIP_CHECK(hipMemcpyAsync(hp, d_player_.p, (size_t)n_ * sizeof(int), hipMemcpyDeviceToHost, st));
+  RBL_HIP_CHECK(hipMemcpyAsync(hi, d_info_.p, sizeof(SpEpochInfo), hipMemcpyDeviceToHost, st));
+  RBL_HIP_CHECK(hipStreamSynchronize(st));
+  e_->end_epoch_device(*hi);
+  games_ = (int64_t)hi->games;
+  std::copy(hb, hb + n_, bid_.begin());
+  std::copy(hp, hp + n_, player_.begin());
+  if (sink) sink(user, (int64_t)2 * n_, ex_lane_.data(), hq, Q, hv, H);
+  return (int64_t)n_ * num_iters;
+}
+
+int64_t SelfPlay::advance_host(rbl_example_fn sink, void* user) {
   const Rules& g = e_->rules();
   const int H = g.H, Q = g.query_size();
   const int num_iters = e_->params().num_iters;
@@ -1364,6 +1628,32 @@ int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user) 
   int64_t n = -1;
   guard([&] { n = need(sp).advance(sink, user); });
   return n;
+}
+int rbl_selfplay_on_device(rbl_selfplay* sp) { return sp ? sp->impl.mode() : -1; }
+int rbl_selfplay_device_examples(rbl_selfplay* sp, const float** queries_dev, const float** values_dev) {
+  return guard([&] {
+    if (!queries_dev || !values_dev) throw std::runtime_error("rbl_selfplay_device_examples: null output pointer");
+    need(sp).device_examples(queries_dev, values_dev);
+  });
+}
+int rbl_selftest_device_rng(int device, int32_t seed, int rounds, int hi, const double* w, int nw, double* out) {
+  return guard([&] {
+    if (rounds < 1 || nw < 1 || !w || !out) throw std::runtime_error("rbl_selftest_device_rng: bad arguments");
+    RBL_HIP_CHECK(hipSetDevice(device));
+    std::vector<uint32_t> st(624);
+    rbl::mt19937_seed_state((uint32_t)seed, st.data());
+    rbl::DevBuf<uint32_t> d_mt;
+    rbl::DevBuf<int> d_idx;
+    rbl::DevBuf<double> d_w, d_out;
+    d_mt.upload(st, nullptr);
+    d_idx.upload(std::vector<int>(1, 624), nullptr);
+    d_w.upload(std::vector<double>(w, w + nw), nullptr);
+    d_out.alloc((size_t)3 * rounds);
+    RBL_HIP_CHECK(hipDeviceSynchronize());
+    rbl::launch_sp_rng_probe(d_mt.p, d_idx.p, 1, 0, rounds, hi, d_w.p, nw, d_out.p, nullptr);
+    RBL_HIP_CHECK(hipGetLastError());
+    RBL_HIP_CHECK(hipMemcpy(out, d_out.p, (size_t)3 * rounds * sizeof(double), hipMemcpyDeviceToHost));
+  });
 }
 int64_t rbl_selfplay_games_finished(rbl_selfplay* sp) { return sp ? sp->impl.games_finished() : -1; }
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id) {

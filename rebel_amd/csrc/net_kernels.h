@@ -44,9 +44,13 @@ bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
 
 // net_resident_kernel.hip (tile 5): persistent workgroups with register-resident weights; one hidden layer of 256 only
 bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out);
-void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
+void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
+                         const long long* range = nullptr);
 
 // out[rows][n_out] = net(queries[rows][n_in]); f16x2-split MFMA (v_mfma_f32_16x16x32_f16), async on `stream`.
-void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream);
+// `range` (optional, device memory): the rows to process are [range[0], range[1]) of queries / out, known only on the
+// device; `rows` is then the host-side upper bound used to size the launch.
+void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
+                        const long long* range = nullptr);
 
 }  // namespace rbl

@@ -103,7 +103,15 @@ constexpr int kFsYStride = 260;    // f32 per row of the pre-activation image (+
 template <int OT, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64, 4) mlp_fsplit_forward_kernel(const MlpDev m,
                                                                           const float* __restrict__ queries,
-                                                                          int64_t rows, float* __restrict__ out) {
+                                                                          int64_t rows, float* __restrict__ out,
+                                                                          const long long* __restrict__ range) {
+  if (range) {  // device-side row range: the launch is sized for the host's upper bound, surplus workgroups leave
+    const long long r0 = range[0], r1 = range[1];
+    queries += r0 * m.n_in;
+    out += r0 * m.n_out;
+    rows = r1 - r0;
+    if ((int64_t)blockIdx.x * (WAVES * 8) >= rows) return;
+  }
   constexpr int KS = 8, RT = WAVES / 2, OTW = 16 / WAVES;  // row tiles per workgroup, output tiles per wave
   constexpr int kFsRows = RT * 16;
   constexpr int kFsLdsBytes = kFsRows * kFsYStride * 4;  // >= the f16x2 activation image (rows x 256 x 4 B)
@@ -483,13 +491,14 @@ MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, 
   return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, 8);
 }
 
-void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
+void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
+                        const long long* range) {
   if (rows <= 0) return;
-  if (m.tile == 5) return launch_mlp_resident(m, queries, rows, out, stream);
+  if (m.tile == 5) return launch_mlp_resident(m, queries, rows, out, stream, range);
   if (m.tile != 3) throw std::runtime_error("launch_mlp_forward: unknown kernel variant");
 #define RBL_FS(OT_) \
   hipLaunchKernelGGL((mlp_fsplit_forward_kernel<OT_, 8>), dim3((unsigned)((rows + 63) / 64)), dim3(512), 0, stream, m, \
-                     queries, rows, out)
+                     queries, rows, out, range)
   switch (m.out_tiles) {
     case 1: RBL_FS(1); break;
     case 2: RBL_FS(2); break;

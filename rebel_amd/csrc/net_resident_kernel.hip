@@ -154,7 +154,15 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
 // K0C: 32-wide k chunks of the input layer (1 for n_in <= 32: its weights stay resident); LN: LayerNorm on / off
 template <int K0C, bool LN>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
-                                                                    int64_t rows, float* __restrict__ out, int n_groups) {
+                                                                    int64_t rows, float* __restrict__ out, int n_groups,
+                                                                    const long long* __restrict__ range) {
+  if (range) {  // device-side row range (resident self-play: the host never learns the row counts of an epoch)
+    const long long r0 = range[0], r1 = range[1];
+    queries += r0 * m.n_in;
+    out += r0 * m.n_out;
+    rows = r1 - r0;
+    n_groups = (int)((rows + kRows - 1) / kRows);
+  }
   constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
   constexpr int kWoF4 = kKS * 2 * 64;             // one output tile's weight fragments (16 KB)
   __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4];
@@ -471,7 +479,8 @@ bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out) {
   return n_layers == 2 && n_hidden == 256 && n_in >= 1 && n_in <= 128 && n_out >= 1 && n_out <= 64;
 }
 
-void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream) {
+void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
+                         const long long* range) {
   static int n_cu[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("launch_mlp_resident: no current device");
@@ -487,10 +496,10 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   do {                                                                                                             \
     if (m.use_ln)                                                                                                  \
       hipLaunchKernelGGL((mlp_resident_kernel<K0C_, true>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries,  \
-                         rows, out, n_groups);                                                                     \
+                         rows, out, n_groups, range);                                                              \
     else                                                                                                           \
       hipLaunchKernelGGL((mlp_resident_kernel<K0C_, false>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
-                         rows, out, n_groups);                                                                     \
+                         rows, out, n_groups, range);                                                              \
   } while (0)
   if (m.out_tiles < 1 || m.out_tiles > 4) throw std::runtime_error("launch_mlp_resident: unsupported n_out");
   switch (m.l0_chunks) {

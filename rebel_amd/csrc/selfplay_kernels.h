@@ -1,0 +1,71 @@
+// rebel_amd/csrc/selfplay_kernels.h -- launch interface of the device-side self-play walk (selfplay_kernels.hip).
+//
+// The recursive-solving outer loop of one reference data-gen thread (RlRunner::step, recursive_solving.cc:160-182;
+// sample_state_to_leaf :192-246; sample_state_single :248-275) runs here for every lane on the GPU, between the CFR
+// launches of two epochs: no per-epoch snapshot read-back, no host walk.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "tables.h"
+
+namespace rbl {
+
+constexpr int kSpMaxParts = 4;
+
+// Written by sp_scan at the start of an epoch, read back (pinned, async) with the examples at its end.
+struct SpEpochInfo {
+  long long part_row[kSpMaxParts + 1];              // net-row boundaries of the lane parts (part p = rows [p, p+1))
+  unsigned long long part_bytes[kSpMaxParts][2];    // algorithmic bytes of one CFR step per part and traverser
+  unsigned long long games;                         // games finished so far (all epochs)
+  long long rows;                                   // = part_row[n_parts]
+};
+
+struct SpArgs {
+  // ---- static tables of the engine (per shape-node, offset by ShapeDev::node_off)
+  const ShapeDev* shapes;
+  const int* act;
+  const int* cb;
+  const int* ce;
+  const int* depth;
+  const int* shape_epar;  // [n_shapes][2]: edges whose parent sits at even / odd depth (roofline accounting)
+  int H, A, Q, liar, Emax, num_iters, n, sample_leaf;
+  float rap;  // random_action_prob as the float the reference compares eps against (recursive_solving.cc:204)
+  // ---- per-lane RNG: std::mt19937 state, [624][n] + position
+  uint32_t* mt;
+  int* mt_idx;
+  // ---- per-lane game state (RlRunner::state_, beliefs_)
+  int* bid;
+  int* player;
+  double* beliefs;  // [n][2][H]
+  // ---- the engine's lane descriptors for the epoch (outputs of sp_begin / sp_scan)
+  int* lane_shape;
+  int* lane_player;
+  int* lane_row;
+  int* lane_act;
+  double* eng_beliefs;  // [n][2][H] root beliefs of the epoch's subgames
+  // ---- inputs of sp_end
+  const double* snapshot;   // [n][Emax*H] sigma_last at act_iteration
+  const double* root_mean;  // [n][2][H]
+  // ---- outputs of sp_end: the epoch's training examples, lane-major, 2 per lane (update_value_network)
+  float* ex_q;  // [2n][Q]
+  float* ex_v;  // [2n][H]
+  SpEpochInfo* info;
+  int n_parts;
+  int part_lane[kSpMaxParts + 1];
+};
+
+// host: the state std::mt19937(seed) starts from (position 624: the first draw twists)
+void mt19937_seed_state(uint32_t seed, uint32_t* state624);
+
+void launch_sp_begin(const SpArgs& a, hipStream_t st);  // reset finished games, draw act_iteration, descriptors
+void launch_sp_scan(const SpArgs& a, hipStream_t st);   // lane_row prefix sums, part boundaries, byte accounting
+void launch_sp_end(const SpArgs& a, hipStream_t st);    // sampling walk, Bayes updates, examples
+
+// test hook: n_draws of each kind from one lane's generator, in this order per round: uniform_int(0, hi), canonical
+// float, discrete over `w` (nw weights)  -> out[3 * rounds] as doubles
+void launch_sp_rng_probe(uint32_t* mt, int* mt_idx, int n, int lane, int rounds, int hi, const double* w, int nw,
+                         double* out, hipStream_t st);
+
+}  // namespace rbl

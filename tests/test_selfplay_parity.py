@@ -13,17 +13,19 @@ from tests.cases import RL_CASES
 pytestmark = pytest.mark.gpu
 
 
-def _run_lanes(c, seeds, games):
+def _run_lanes(c, seeds, games, expect_device=1):
     from rebel_amd import capi
 
     e = capi.Engine(c["d"], c["f"], capi.make_params(**c["p"]), max_lanes=len(seeds))
     e.set_net_synthetic() if c["net"] == "synthetic" else e.set_net_zero()
     sp = capi.SelfPlay(e, seeds, random_action_prob=c["rap"], sample_leaf=c["leaf"])
+    assert sp.on_device() == -1
     per_lane = [[] for _ in seeds]
     done_at = [None] * len(seeds)  # number of examples when the lane finished `games` games
     finished = [0] * len(seeds)
     while any(d is None for d in done_at):
         _, lanes, q, v = sp.advance()
+        assert sp.on_device() == expect_device  # the walk itself ran as HIP kernels (or on the host when asked to)
         for k in range(len(lanes)):
             per_lane[lanes[k]].append((q[k], v[k]))
         for i in range(len(seeds)):
@@ -113,3 +115,65 @@ def test_selfplay_fictitious_play_lanes(port):
         assert len(ex) == len(ref), seed
         for (q, v), (rq, rv) in zip(ex, ref):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
+
+
+@pytest.mark.parametrize("seed,hi,weights", [
+    (0, 1, [0.5, 0.5]), (7, 1024, [0.1, 0.2, 0.7]), (123456789, 12, [1e-80, 0.3, 0.0, 0.69, 1e-9, 0.01]),
+    (-5, 5, [3.0, 1.0, 0.0, 0.0, 2.5, 9.25, 1e-300]), (2**31 - 1, 2**31 - 2, [1.0]), (42, 0, [0.0, 0.0, 1.0])])
+def test_device_rng_matches_libstdcxx_draw_for_draw(seed, hi, weights, port):
+    """The device restatement of std::mt19937 + uniform_int / uniform_real<float> / discrete distributions
+    (selfplay_kernels.hip) against the host library the reference links: 3 x 1500 draws cross several state twists
+    (624 words each) and the Lemire rejection branch; a single weight draws nothing (libstdc++ returns 0)."""
+    from rebel_amd import capi
+
+    got = capi.device_rng_draws(seed, 1500, hi, weights)
+    ref = port.rng_probe(seed, 1500, hi, weights)
+    assert np.array_equal(got, ref)
+
+
+def test_device_walk_equals_host_walk(monkeypatch):
+    """Same seeds through the device walk and the legacy host walk (RBL_SELFPLAY_HOST=1, the path callback nets use):
+    identical example streams, sample_leaf on and off."""
+    for leaf in (True, False):
+        c = dict(d=1, f=6, p=dict(num_iters=40, max_depth=2, linear_update=True, use_cfr=True), rap=0.35, leaf=leaf,
+                 net="synthetic")
+        seeds = list(range(900, 900 + 48))
+        dev = _run_lanes(c, seeds, 3)
+        monkeypatch.setenv("RBL_SELFPLAY_HOST", "1")
+        host = _run_lanes(c, seeds, 3, expect_device=0)
+        monkeypatch.delenv("RBL_SELFPLAY_HOST")
+        for a, b in zip(dev, host):
+            assert len(a) == len(b)
+            for (q, v), (rq, rv) in zip(a, b):
+                assert np.array_equal(q, rq) and np.array_equal(v, rv)
+
+
+def test_selfplay_games_counter_and_callback_net_falls_back_to_host(port):
+    """games_finished counts terminal states on the device; a callback net (teacher-forced oracle values) keeps the host
+    walk and still reproduces the oracle."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    p = dict(num_iters=16, max_depth=2, linear_update=True, use_cfr=True)
+    e = capi.Engine(1, 4, capi.make_params(**p), max_lanes=32)
+    e.set_net_synthetic()
+    sp = capi.SelfPlay(e, list(range(32)), random_action_prob=0.25, sample_leaf=True)
+    finished = 0
+    for _ in range(12):
+        sp.advance()
+        finished += sum(1 for i in range(32) if sp.state(i)[0] == e.A - 1)
+    assert sp.on_device() == 1 and sp.games_finished() == finished > 0
+    e2 = capi.Engine(1, 4, capi.make_params(**p), max_lanes=4)
+    e2.set_net_callback(lambda q: port.synthetic_net(q, e2.A, e2.H))
+    sp2 = capi.SelfPlay(e2, [11, 12, 13, 14], random_action_prob=0.25, sample_leaf=True)
+    got = [[] for _ in range(4)]
+    for _ in range(6):
+        _, lanes, q, v = sp2.advance()
+        for k in range(len(lanes)):
+            got[lanes[k]].append((q[k], v[k]))
+    assert sp2.on_device() == 0
+    for i, seed in enumerate([11, 12, 13, 14]):
+        ref = port.rl_run(1, 4, orc.make_params(**p), seed, 6, random_action_prob=0.25, sample_leaf=True,
+                          net=orc.NET_SYNTHETIC)
+        for (q, v), (rq, rv) in zip(got[i], ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv)
