@@ -6,19 +6,23 @@
 
 Metric (BASELINE.json): subgame CFR iterations/sec, whole job, 1 die x 6 faces @ 1024 iterations per subgame.
 A "step" is one pass of the hot path over one batch: EVERY lane plays one subgame of its self-play game end to end --
-build_solver, 1024 x [batched value-net forward on MFMA + CFR step kernel], sigma snapshot at the lane's act_iteration,
-host-side sampling of the next public state (libstdc++ <random>, the reference's draw order), 2 training examples per
-lane handed to the example sink.  One step = lanes x 1024 subgame-CFR-iterations.  Work is sharded across GPUs as
-independent lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
+RlRunner::step's draws and solver construction (device kernels), 1024 x [batched value-net forward on MFMA + CFR step
+kernel], sigma snapshot at the lane's act_iteration, the sampling walk to the next public state and the Bayes updates
+(device kernels, libstdc++ <random> restated draw for draw), 2 training examples per lane handed to the example sink
+(the only read-back).  One step = lanes x 1024 subgame-CFR-iterations.  Work is sharded across GPUs as independent
+lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
-                measured live with HIP events on the engine streams (every 8th iteration of the timed region; the
-                two half-batches run on two streams, so a launch covers half the lanes and shares the GPU with the other
-                half's CFR kernel whenever that one finds free registers)
-  roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration
-  cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so, cpu_gen_threads = host cores) timed for a fixed
-                window on this box's host cores -- a reported baseline, not a target.
+                measured live with HIP events on the engine streams over the timed region (every 8th iteration; the two
+                half-batches run on two streams, so a launch covers half the lanes and is time-sliced against the other
+                half's CFR kernel: "in-mix"), plus `standalone`: the same kernel timed in a short extra leg where the
+                launches of an iteration run back to back on ONE stream (what the kernel does when it owns the GPU)
+  roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration, in-mix + standalone
+  traffic       HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, separate
+                --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH x2 per the gfx950 note of the guide)
+  cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so) timed on this box's host cores for >= 30 s per
+                generator-thread count in {16, 32, 60 (README), os.cpu_count()} -- a reported baseline, not a target.
 """
 import argparse
 import json
@@ -65,12 +69,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("BENCH_LANES", 4096)))
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("BENCH_LANES", 16384)))
     ap.add_argument("--iters", type=int, default=int(os.environ.get("BENCH_ITERS", 1024)))
     ap.add_argument("--dice", type=int, default=1)
     ap.add_argument("--faces", type=int, default=6)
-    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("BENCH_CPU_SECONDS", 20)))
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("BENCH_CPU_SECONDS", 120)),
+                    help="total CPU-baseline window, split over the generator-thread counts (>= 30 s each by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the stand-alone kernel leg and the 4096-lane comparison leg (profiling runs)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank")
     a = ap.parse_args()
 
@@ -98,44 +105,94 @@ def main():
     torch.manual_seed(0)  # same random-init net on every rank (weights are read-only shared state)
     net = Net2(num_faces=a.faces, num_dice=a.dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
     params = capi.make_params(num_iters=a.iters, max_depth=2, linear_update=True, use_cfr=True)
-    eng = capi.Engine(a.dice, a.faces, params, max_lanes=a.lanes, device=local_rank)
-    eng.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
-    seeds = lane_seeds(rank, a.lanes)
-    sp = capi.SelfPlay(eng, seeds, random_action_prob=0.25, sample_leaf=True)
+    weights = mlp_weights_from_state_dict(net.state_dict())
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        sp.advance(collect=False)
-    eng.sync()
-    eng.stats(reset=True)
-    eng.timing(8)
-    n_examples, games0 = 0, sp.games_finished()
-    barrier()
-    t0 = time.perf_counter()
-    units = 0
-    for _ in range(a.steps):
-        n, lanes, q, v = sp.advance(collect=True)  # examples land in host arrays = the replay push hand-off
-        units += n
-        n_examples += len(lanes)
-    eng.sync()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = eng.stats(reset=True)
-    eng.timing(0)
-    games = sp.games_finished() - games0
+    def run_leg(lanes, warmup, steps, timing_stride, sync_ranks):
+        """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
+        eng = capi.Engine(a.dice, a.faces, params, max_lanes=lanes, device=local_rank)
+        eng.set_net_mlp(*weights)
+        sp = capi.SelfPlay(eng, lane_seeds(rank, lanes), random_action_prob=0.25, sample_leaf=True)
+        for _ in range(warmup):
+            sp.advance(collect=False)
+        eng.sync()
+        eng.stats(reset=True)
+        eng.timing(timing_stride)
+        n_ex, games0, units = 0, sp.games_finished(), 0
+        if sync_ranks:
+            barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            n, lanes_, q, v = sp.advance(collect=True)  # examples land in host arrays = the replay push hand-off
+            units += n
+            n_ex += len(lanes_)
+        eng.sync()
+        if sync_ranks:
+            barrier()
+        dt = time.perf_counter() - t0
+        st = eng.stats(reset=True)
+        eng.timing(0)
+        games = sp.games_finished() - games0
+        on_device = sp.on_device()
+        sp.close()
+        eng.close()
+        return dt, units, games, n_ex, st, on_device
+
+    dt, units, games, n_examples, st, walk_on_device = run_leg(a.lanes, a.warmup, a.steps, 8, True)
 
     dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
                                               float(games)) if use_dist else (dt, float(units), float(games))
 
-    if rank == 0:
+    def kernel_figures(st):
         net_t = st["net_ms"] / max(1, st["net_launches"]) * 1e-3
         cfr_t = st["cfr_ms"] / max(1, st["cfr_launches"]) * 1e-3
         net_tf = st["net_flops"] / max(1, st["net_launches"]) / net_t / 1e12 if net_t > 0 else 0.0
         cfr_gb = st["cfr_bytes"] / max(1, st["cfr_launches"]) / cfr_t / 1e9 if cfr_t > 0 else 0.0
+        return net_t, cfr_t, net_tf, cfr_gb
+
+    standalone = lanes4096 = None
+    if world == 1 and not a.no_extra_legs:
+        # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
+        os.environ["RBL_PARTS"] = "1"
+        sdt, sunits, _, _, sst, _ = run_leg(a.lanes, 1, 2, 4, False)
+        del os.environ["RBL_PARTS"]
+        s_net_t, s_cfr_t, s_net_tf, s_cfr_gb = kernel_figures(sst)
+        standalone = {"net": {"avg_launch_us": s_net_t * 1e6, "rows_per_launch": sst["net_rows"] / max(1, sst["net_launches"]),
+                              "achieved": s_net_tf, "frac": s_net_tf / MFMA_F16_PEAK_TFLOPS,
+                              "ns_per_row": s_net_t * 1e9 / max(1.0, sst["net_rows"] / max(1, sst["net_launches"]))},
+                      "cfr": {"avg_launch_us": s_cfr_t * 1e6, "achieved": s_cfr_gb, "frac": s_cfr_gb / HBM_PEAK_GBPS},
+                      "value_serial": sunits / sdt,
+                      "note": "RBL_PARTS=1: one stream, net(all lanes) -> cfr(all lanes) per iteration; 1 warm-up + 2 timed "
+                              "epochs from the root state (root-heavy mix: more rows per lane than the steady state)"}
+        if a.lanes != 4096:
+            ldt, lunits, _, _, _, _ = run_leg(4096, 2, 3, 0, False)
+            lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count), 2 warm-up + "
+                         "3 timed epochs"}
+
+    def pmc_traffic(kernel_key):
+        """HBM-side bytes per launch of `kernel_key` from the newest committed PMC summary (scripts/collect_profiles.sh)."""
+        import glob
+
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                d = json.load(open(path))
+            except Exception:
+                continue
+            for name, k in d.get("kernels", {}).items():
+                if kernel_key in name and "fetch_size_bytes_per_launch" in k and "write_size_bytes_per_launch" in k:
+                    return {"bytes": k["fetch_size_bytes_per_launch"]["median"] + k["write_size_bytes_per_launch"]["median"],
+                            "read": k["fetch_size_bytes_per_launch"]["median"],
+                            "written": k["write_size_bytes_per_launch"]["median"],
+                            "source": os.path.relpath(path, ROOT), "kernel": name,
+                            "lanes_profiled": d.get("lanes"), "note": d.get("note")}
+        return None
+
+    if rank == 0:
+        net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
         H_, A_ = a.faces ** a.dice, 2 * a.dice * a.faces + 1
         Q_ = 2 + A_ + 2 * H_
         issued_ratio = 3.0 * (-(-Q_ // 32) * 32 * 256 + 256 * 256 + 256 * -(-H_ // 16) * 16) / (Q_ * 256 + 256 * 256 + 256 * H_)
@@ -167,14 +224,31 @@ def main():
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
                          "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),
+                         "ns_per_row": net_t * 1e9 / max(1.0, st["net_rows"] / max(1, st["net_launches"])),
+                         "algorithmic_flops_per_launch": st["net_flops"] / max(1, st["net_launches"]),
+                         "measured": "in-mix: HIP events on the launch's own stream, the other stream's CFR kernel active",
                          "issued_mfma_tflops": net_tf * issued_ratio,
                          "vs_f32_mfma_peak": net_tf / MFMA_F32_PEAK_TFLOPS},
             "roofline_cfr": {"kernel": "cfr_rows_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
-                             "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"]},
+                             "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"],
+                             "algorithmic_bytes_per_launch": st["cfr_bytes"] / max(1, st["cfr_launches"]),
+                             "measured": "in-mix: HIP events on the launch's own stream, the other stream's net kernel active"},
+            "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
         }
+        for key, kern in (("roofline", "mlp_resident_kernel"), ("roofline_cfr", "cfr_")):
+            tr = pmc_traffic(kern)
+            if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
+                scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0
+                out[key]["traffic"] = tr["bytes"] * scale
+                out[key]["traffic_detail"] = tr
+        if standalone:
+            out["roofline"]["standalone"] = standalone["net"]
+            out["roofline_cfr"]["standalone"] = standalone["cfr"]
+            out["standalone_leg"] = {k: standalone[k] for k in ("value_serial", "note")}
+        if lanes4096:
+            out["lanes_4096"] = lanes4096
         if world == 1 and not a.no_cpu_baseline:
-            del sp, eng
             out["cpu_baseline"] = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

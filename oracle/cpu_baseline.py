@@ -41,9 +41,10 @@ def main():
     ap.add_argument("--faces", type=int, default=6)
     ap.add_argument("--iters", type=int, default=1024)
     ap.add_argument("--threads", type=int, default=0,
-                    help="generator threads; 0 = sweep {16, 32, 60} capped at os.cpu_count() and report the best "
-                         "(60 is the README's cpu_gen_threads setting; the reference path stops scaling well before that)")
-    ap.add_argument("--seconds", type=float, default=20.0)
+                    help="generator threads; 0 = sweep {16, 32, 60, os.cpu_count()} and report the best (60 is the "
+                         "README's cpu_gen_threads setting, os.cpu_count() what BASELINE.md section 3 plans; the reference "
+                         "path stops scaling well before either)")
+    ap.add_argument("--seconds", type=float, default=120.0, help="total window, split evenly over the thread counts")
     ap.add_argument("--warmup", type=float, default=3.0)
     ap.add_argument("--single", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
@@ -52,7 +53,7 @@ def main():
         return 2
     if not a.single:
         cores = os.cpu_count() or 1
-        counts = [a.threads] if a.threads else sorted({min(c, cores) for c in (16, 32, 60)})
+        counts = [a.threads] if a.threads else sorted({min(c, cores) for c in (16, 32, 60, cores)})
         a.seconds = a.seconds / len(counts)
         runs = [run_once(a, T) for T in counts]
         good = [r for r in runs if "value" in r]
@@ -74,9 +75,14 @@ def main():
     T = a.threads
     torch.manual_seed(0)
     net = Net2(num_faces=a.faces, num_dice=a.dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    import io
+
+    buf = io.BytesIO()  # script once, load T replicas (one per generator thread, as selfplay.py:187-221 does)
+    torch.jit.save(torch.jit.script(net), buf)
     models, lockers = [], []
     for _ in range(T):
-        m = torch.jit.script(net)
+        buf.seek(0)
+        m = torch.jit.load(buf)
         models.append(m)
         lockers.append(rela.ModelLocker([m], "cpu"))
     replay = rela.ValuePrioritizedReplay(capacity=2 ** 20, seed=10001, alpha=1.0, beta=0.4, prefetch=3,

@@ -52,6 +52,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_sessionfinish(session, exitstatus):
+    """Native code (the compiled reference's progress prints) writes to C stdio; flush it before pytest prints its
+    summary so that the `N passed` line stays the last line of the log."""
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def _gpu_preflight():
     """Runs the preflight in fresh processes; returns normally once one attempt succeeds."""
     attempts = []
