@@ -144,7 +144,8 @@ void rbl_selfplay_destroy(rbl_selfplay* sp);
  * as HIP kernels between the CFR launches (selfplay_kernels.hip); the host only receives the examples.  With a callback
  * net (rbl_engine_set_net_callback) or RBL_SELFPLAY_HOST=1 the walk runs on the host instead: same trajectories. */
 int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user);
-/* 1 if the lanes' walk runs on the device (decided at the first advance), 0 on the host, -1 before the first advance */
+/* 1 if the lanes' walk runs on the device, 0 on the host; the choice is made from the engine's net at the first call of
+ * this function or of rbl_selfplay_advance, whichever comes first, and then stays.  -1 on error. */
 int rbl_selfplay_on_device(rbl_selfplay* sp);
 /* Device pointers to the LAST epoch's examples, queries [2*n_lanes][Q] and values [2*n_lanes][H] f32, valid until the next
  * advance (replaces per-example tensor allocation, subgame_solving.cc:220-226, for a device-resident replay buffer);

@@ -403,7 +403,7 @@ class SelfPlay:
         return self.e.L.rbl_selfplay_games_finished(self.h)
 
     def on_device(self):
-        """1: the sampling walk runs as HIP kernels; 0: on the host (callback net / RBL_SELFPLAY_HOST=1); -1: undecided."""
+        """1: the sampling walk runs as HIP kernels; 0: on the host (callback net / RBL_SELFPLAY_HOST=1).  Decides on first use."""
         return self.e.L.rbl_selfplay_on_device(self.h)
 
     def state(self, lane):

@@ -221,7 +221,7 @@ class SelfPlay {
   SelfPlay(const SelfPlay&) = delete;
   SelfPlay& operator=(const SelfPlay&) = delete;
   int64_t advance(rbl_example_fn sink, void* user);
-  int mode() const { return mode_; }
+  int decide_mode();  // fixes host / device walk from the engine's current net (first call), returns 0 / 1
   bool on_device() const { return mode_ == 1; }  // the walk runs as kernels (selfplay_kernels.hip), decided at the first advance()
   // the last epoch's examples as device pointers ([2n][Q], [2n][H]), valid until the next advance(); null in host mode
   void device_examples(const float** q, const float** v) const;

@@ -1228,7 +1228,7 @@ void SelfPlay::device_examples(const float** q, const float** v) const {
 // The walk runs on the device unless the value net is a host/device callback (the net launch then needs host-side row
 // counts every iteration) or RBL_SELFPLAY_HOST=1 asks for the host walk (A/B: both produce identical trajectories,
 // tests/test_selfplay_parity.py).  Decided once, at the first epoch: the two modes keep separate RNG states.
-int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
+int SelfPlay::decide_mode() {
   if (mode_ < 0) {
     const Rules& g = e_->rules();
     const bool ok = e_->device_epochs_supported() && !env_int("RBL_SELFPLAY_HOST", 0) && g.H <= 64 && g.A <= 64 &&
@@ -1236,6 +1236,11 @@ int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
     mode_ = ok ? 1 : 0;
     if (mode_ == 1) init_device();
   }
+  return mode_;
+}
+
+int64_t SelfPlay::advance(rbl_example_fn sink, void* user) {
+  decide_mode();
   if (mode_ == 1) {
     if (!e_->device_epochs_supported())
       throw std::runtime_error("selfplay: the value net became a callback net after device self-play started; create "
@@ -1333,8 +1338,10 @@ int64_t SelfPlay::advance_device(rbl_example_fn sink, void* user) {
   int* hb = reinterpret_cast<int*>(hv + (size_t)2 * n_ * H);
   int* hp = hb + n_;
   SpEpochInfo* hi = reinterpret_cast<SpEpochInfo*>(hp + n_);
-  RBL_HIP_CHECK(hipMemcpyAsync(hq, d_ex_q_.p, (size_t)2 * n_ * Q * sizeof(float), hipMemcpyDeviceToHost, st));
-  RBL_HIP_CHECK(hipMemcpyAsync(hv, d_ex_v_.p, (size_t)2 * n_ * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (sink) {  // without a sink the examples stay on the device (rbl_selfplay_device_examples)
+    RBL_HIP_CHECK(hipMemcpyAsync(hq, d_ex_q_.p, (size_t)2 * n_ * Q * sizeof(float), hipMemcpyDeviceToHost, st));
+    RBL_HIP_CHECK(hipMemcpyAsync(hv, d_ex_v_.p, (size_t)2 * n_ * H * sizeof(float), hipMemcpyDeviceToHost, st));
+  }
   RBL_HIP_CHECK(hipMemcpyAsync(hb, d_bid_.p, (size_t)n_ * sizeof(int), hipMemcpyDeviceToHost, st));
   RBL_HIP_CHECK(hipMemcpyAsync(hp, d_player_.p, (size_t)n_ * sizeof(int), hipMemcpyDeviceToHost, st));
   RBL_HIP_CHECK(hipMemcpyAsync(hi, d_info_.p, sizeof(SpEpochInfo), hipMemcpyDeviceToHost, st));
@@ -1629,7 +1636,11 @@ int64_t rbl_selfplay_advance(rbl_selfplay* sp, rbl_example_fn sink, void* user) 
   guard([&] { n = need(sp).advance(sink, user); });
   return n;
 }
-int rbl_selfplay_on_device(rbl_selfplay* sp) { return sp ? sp->impl.mode() : -1; }
+int rbl_selfplay_on_device(rbl_selfplay* sp) {
+  int m = -1;
+  guard([&] { m = need(sp).decide_mode(); });
+  return m;
+}
 int rbl_selfplay_device_examples(rbl_selfplay* sp, const float** queries_dev, const float** values_dev) {
   return guard([&] {
     if (!queries_dev || !values_dev) throw std::runtime_error("rbl_selfplay_device_examples: null output pointer");

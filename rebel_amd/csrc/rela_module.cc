@@ -12,8 +12,12 @@
 //     A module that is not Net2-shaped still works: its TorchScript forward is called on the GPU for the whole batch.
 //   * ValuePrioritizedReplay keeps the reference's semantics (rela/prioritized_replay.h:224-504: 1.25x ring, blocking
 //     add, in-order publish, stratified priority sampling / uniform sampling, trim-on-sample, prefetch futures, file
-//     format of rela/types.cc:87-111) over flat float rings instead of a vector of tiny tensors, so the engine pushes
-//     all examples of an epoch with one block append.
+//     format of rela/types.cc:87-111) over two flat [ring][Q] / [ring][H] float rings instead of a vector of tiny
+//     tensors.  The rings live where the examples are produced: an engine whose self-play walk runs on the device
+//     appends an epoch's examples with device-to-device block copies straight out of the walk kernel's output buffer
+//     (add_block_device), and sample() gathers the batch on that GPU (index_select) and returns device tensors; rings
+//     fed from the host (push / load / host-walk engines) stay in host memory.  Which slot holds what, the weights
+//     and every random draw stay on the host, so the sampled indices are the reference's for the same seed.
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 #include <torch/extension.h>
@@ -116,39 +120,32 @@ class ValuePrioritizedReplay {
 
   // ---- producer side: PrioritizedReplay::add (:247-261) -> ConcurrentQueue::blockAppend (:59-96)
   // `stop` lets a generator that is being terminated leave a full buffer (the reference would block forever).
+  // A block is appended in chunks of at most ring - capacity slots: sample() only trims the ring back to `capacity`, so
+  // that is the largest request a full buffer is guaranteed to admit eventually (the reference appends one example at a
+  // time and cannot starve; an epoch of a few thousand lanes against a small buffer could).
   bool add_block(const float* q, int64_t Q, const float* v, int64_t V, int64_t n, const float* priority,
                  const std::atomic<bool>* stop = nullptr) {
-    if (n <= 0) return true;
-    if (n > ring_) fail("replay: block larger than the buffer");
-    std::unique_lock<std::mutex> lk(m_);
-    ensure_layout(Q, V);
-    while (!(size_ + n <= ring_)) {
-      if (stop && stop->load()) return false;
-      cv_size_.wait_for(lk, std::chrono::milliseconds(50));
+    const int64_t chunk = std::max<int64_t>(1, ring_ - capacity_);
+    for (int64_t s = 0; s < n; s += chunk) {
+      const int64_t k = std::min(chunk, n - s);
+      if (!append(q + s * Q, Q, v + s * V, V, k, priority ? priority + s : nullptr, -1, stop)) return false;
     }
-    const int start = tail_;
-    const int end = (int)((tail_ + n) % ring_);
-    tail_ = end;
-    size_ += (int)n;
-    lk.unlock();
-    double sum = 0;
-    for (int64_t i = 0; i < n; ++i) {  // copy outside the lock, as the reference does
-      const int j = (int)((start + i) % ring_);
-      std::memcpy(&q_[(size_t)j * Q_], q + i * Q, sizeof(float) * Q);
-      std::memcpy(&v_[(size_t)j * V_], v + i * V, sizeof(float) * V);
-      const float w = use_priority_ ? std::pow(priority[i], alpha_) : priority[i];
-      weights_[j] = w;
-      sum += w;
-    }
-    lk.lock();
-    cv_tail_.wait(lk, [&] { return safe_tail_ == start; });  // publish in reservation order
-    safe_tail_ = end;
-    safe_size_ += (int)n;
-    sum_ += sum;
-    lk.unlock();
-    cv_tail_.notify_all();
-    num_add_ += (int)n;
     return true;
+  }
+  // The same for examples that already sit in GPU memory (rbl_selfplay_device_examples): priorities are all 1
+  // (CVNetBufferConnector passes ones, rela/data_loop.h:50-55).  The first device block moves the rings to that GPU.
+  bool add_block_device(const float* q_dev, int64_t Q, const float* v_dev, int64_t V, int64_t n, int device_index,
+                        const std::atomic<bool>* stop = nullptr) {
+    const int64_t chunk = std::max<int64_t>(1, ring_ - capacity_);
+    for (int64_t s = 0; s < n; s += chunk) {
+      const int64_t k = std::min(chunk, n - s);
+      if (!append(q_dev + s * Q, Q, v_dev + s * V, V, k, nullptr, device_index, stop)) return false;
+    }
+    return true;
+  }
+  std::string storage_device() const {
+    std::lock_guard<std::mutex> lk(m_);
+    return Q_ < 0 ? std::string("unallocated") : tq_.device().str();
   }
 
   int size() const {  // safeSize (:49-55)
@@ -217,11 +214,15 @@ class ValuePrioritizedReplay {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) fail("replay.save: cannot open " + path);
     const int qn = (int)Q_, vn = (int)V_;
-    for (int i = 0; i < size_; ++i) {
-      std::fwrite(&qn, sizeof(int), 1, f);
-      std::fwrite(&vn, sizeof(int), 1, f);
-      std::fwrite(&q_[(size_t)i * Q_], sizeof(float), Q_, f);
-      std::fwrite(&v_[(size_t)i * V_], sizeof(float), V_, f);
+    if (size_ > 0) {
+      const auto hq = tq_.narrow(0, 0, size_).to(torch::kCPU).contiguous();
+      const auto hv = tv_.narrow(0, 0, size_).to(torch::kCPU).contiguous();
+      for (int i = 0; i < size_; ++i) {
+        std::fwrite(&qn, sizeof(int), 1, f);
+        std::fwrite(&vn, sizeof(int), 1, f);
+        std::fwrite(hq.data_ptr<float>() + (size_t)i * Q_, sizeof(float), Q_, f);
+        std::fwrite(hv.data_ptr<float>() + (size_t)i * V_, sizeof(float), V_, f);
+      }
     }
     std::fclose(f);
   }
@@ -255,14 +256,20 @@ class ValuePrioritizedReplay {
       size = safe_size_;
       head = head_;
     }
-    auto q = torch::empty({size, (int64_t)Q_}, torch::kFloat32);
-    auto v = torch::empty({size, (int64_t)V_}, torch::kFloat32);
     auto w = torch::empty({size}, torch::kFloat32);
+    auto idx = torch::empty({size}, torch::kInt64);
     for (int i = 0; i < size; ++i) {
       const int j = (head + i) % ring_;
-      if (Q_) std::memcpy(q.data_ptr<float>() + (size_t)i * Q_, &q_[(size_t)j * Q_], sizeof(float) * Q_);
-      if (V_) std::memcpy(v.data_ptr<float>() + (size_t)i * V_, &v_[(size_t)j * V_], sizeof(float) * V_);
+      idx.data_ptr<int64_t>()[i] = j;
       w.data_ptr<float>()[i] = weights_[j];
+    }
+    torch::Tensor q, v;
+    if (Q_ < 0) {
+      q = torch::empty({0, 0}, torch::kFloat32);
+      v = torch::empty({0, 0}, torch::kFloat32);
+    } else {
+      q = tq_.index_select(0, idx.to(tq_.device())).to(torch::kCPU);
+      v = tv_.index_select(0, idx.to(tv_.device())).to(torch::kCPU);
     }
     block_pop(size);
     return {q, v, torch::pow(w, 1 / alpha_)};
@@ -270,31 +277,101 @@ class ValuePrioritizedReplay {
 
   void push(std::vector<torch::Tensor> data) {  // :347-353
     if (data.size() != 3) fail("replay.push: expected [query, values, weights]");
-    auto q = data[0].to(torch::kCPU, torch::kFloat32).contiguous();
-    auto v = data[1].to(torch::kCPU, torch::kFloat32).contiguous();
+    const bool on_gpu = data[0].is_cuda() && data[1].is_cuda() && data[0].device() == data[1].device();
+    auto q = on_gpu ? data[0].to(torch::kFloat32).contiguous() : data[0].to(torch::kCPU, torch::kFloat32).contiguous();
+    auto v = on_gpu ? data[1].to(torch::kFloat32).contiguous() : data[1].to(torch::kCPU, torch::kFloat32).contiguous();
     auto w = data[2].to(torch::kCPU, torch::kFloat32).contiguous();
     if (q.dim() != 2 || v.dim() != 2 || w.dim() != 1 || q.size(0) != v.size(0) || q.size(0) != w.size(0))
       fail("replay.push: shapes must be [n,Q], [n,V], [n]");
-    const int64_t n = q.size(0), chunk = std::max<int64_t>(1, ring_ / 4);
+    if (on_gpu) torch::cuda::synchronize(q.device().index());  // the copies below read the tensors through raw pointers
+    const int dev = on_gpu ? (int)q.device().index() : -1;     // device tensors go into the device ring without a host hop
+    const int64_t n = q.size(0), chunk = std::max<int64_t>(1, ring_ - capacity_);
     for (int64_t s = 0; s < n; s += chunk) {
       const int64_t k = std::min(chunk, n - s);
-      add_block(q.data_ptr<float>() + s * q.size(1), q.size(1), v.data_ptr<float>() + s * v.size(1), v.size(1), k,
-                w.data_ptr<float>() + s);
+      append(q.data_ptr<float>() + s * q.size(1), q.size(1), v.data_ptr<float>() + s * v.size(1), v.size(1), k,
+             w.data_ptr<float>() + s, dev, nullptr);
     }
   }
 
  private:
   using Sampled = std::tuple<ValueTransition, torch::Tensor, std::vector<int>>;
 
-  void ensure_layout(int64_t Q, int64_t V) {  // m_ held
+  // One chunk: reserve [start, start + n) under the lock, copy outside it (as the reference does), publish in reservation
+  // order.  device_index < 0: q / v are host pointers; >= 0: device pointers on that GPU.
+  bool append(const float* q, int64_t Q, const float* v, int64_t V, int64_t n, const float* priority, int device_index,
+              const std::atomic<bool>* stop) {
+    if (n <= 0) return true;
+    if (n > ring_) fail("replay: block larger than the buffer");
+    std::unique_lock<std::mutex> lk(m_);
+    ensure_layout(Q, V, device_index);
+    while (!(size_ + n <= ring_)) {
+      if (stop && stop->load()) return false;
+      cv_size_.wait_for(lk, std::chrono::milliseconds(50));
+    }
+    const int start = tail_;
+    const int end = (int)((tail_ + n) % ring_);
+    tail_ = end;
+    size_ += (int)n;
+    const torch::Tensor tq = tq_, tv = tv_;  // the rings may be re-homed by another producer; these handles stay valid
+    lk.unlock();
+    double sum = 0;
+    const int64_t first = std::min<int64_t>(n, ring_ - start);  // the block may wrap around the end of the ring
+    if (device_index < 0 && tq.device().is_cpu()) {
+      for (int64_t i = 0; i < n; ++i) {
+        const int j = (int)((start + i) % ring_);
+        std::memcpy(tq.data_ptr<float>() + (size_t)j * Q_, q + i * Q, sizeof(float) * Q);
+        std::memcpy(tv.data_ptr<float>() + (size_t)j * V_, v + i * V, sizeof(float) * V);
+      }
+    } else {
+      auto opt = torch::TensorOptions().dtype(torch::kFloat32);
+      if (device_index >= 0) opt = opt.device(torch::kCUDA, device_index);
+      const auto sq = torch::from_blob(const_cast<float*>(q), {n, Q}, opt);
+      const auto sv = torch::from_blob(const_cast<float*>(v), {n, V}, opt);
+      tq.narrow(0, start, first).copy_(sq.narrow(0, 0, first));
+      tv.narrow(0, start, first).copy_(sv.narrow(0, 0, first));
+      if (first < n) {
+        tq.narrow(0, 0, n - first).copy_(sq.narrow(0, first, n - first));
+        tv.narrow(0, 0, n - first).copy_(sv.narrow(0, first, n - first));
+      }
+      // the rows must be in place before they are published, and the source buffer is reused by the next epoch
+      if (tq.device().is_cuda()) torch::cuda::synchronize(tq.device().index());
+      if (device_index >= 0 && !(tq.device().is_cuda() && tq.device().index() == device_index))
+        torch::cuda::synchronize(device_index);
+    }
+    for (int64_t i = 0; i < n; ++i) {
+      const int j = (int)((start + i) % ring_);
+      const float p = priority ? priority[i] : 1.0f;
+      const float w = use_priority_ ? std::pow(p, alpha_) : p;
+      weights_[j] = w;
+      sum += w;
+    }
+    lk.lock();
+    cv_tail_.wait(lk, [&] { return safe_tail_ == start; });  // publish in reservation order
+    safe_tail_ = end;
+    safe_size_ += (int)n;
+    sum_ += sum;
+    lk.unlock();
+    cv_tail_.notify_all();
+    num_add_ += (int)n;
+    return true;
+  }
+
+  void ensure_layout(int64_t Q, int64_t V, int device_index) {  // m_ held
+    const bool want_gpu = device_index >= 0 && !std::getenv("REBEL_AMD_REPLAY_HOST");
     if (Q_ < 0) {
       Q_ = Q;
       V_ = V;
-      q_.assign((size_t)ring_ * Q_, 0.f);
-      v_.assign((size_t)ring_ * V_, 0.f);
+      auto opt = torch::TensorOptions().dtype(torch::kFloat32);
+      if (want_gpu) opt = opt.device(torch::kCUDA, device_index);
+      tq_ = torch::zeros({(int64_t)ring_, Q_}, opt);
+      tv_ = torch::zeros({(int64_t)ring_, V_}, opt);
     } else if (Q != Q_ || V != V_) {
       fail("replay: transition width changed (" + std::to_string(Q) + "," + std::to_string(V) + ") vs (" +
            std::to_string(Q_) + "," + std::to_string(V_) + ")");
+    } else if (want_gpu && tq_.device().is_cpu() && size_ == 0) {
+      // first device block into an (empty) host ring: the rings move to the GPU that produces the data
+      tq_ = tq_.to(torch::Device(torch::kCUDA, device_index));
+      tv_ = tv_.to(torch::Device(torch::kCUDA, device_index));
     }
   }
 
@@ -332,15 +409,25 @@ class ValuePrioritizedReplay {
     }
     if (size <= 0) fail("ValuePrioritizedReplay.sample: buffer is empty");
     ValueTransition batch;
-    batch.query = torch::empty({batchsize, (int64_t)Q_}, torch::kFloat32);
-    batch.values = torch::empty({batchsize, (int64_t)V_}, torch::kFloat32);
+    torch::Tensor tq, tv;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      tq = tq_;
+      tv = tv_;
+    }
+    const bool on_host = tq.device().is_cpu();
+    if (on_host) {
+      batch.query = torch::empty({batchsize, (int64_t)Q_}, torch::kFloat32);
+      batch.values = torch::empty({batchsize, (int64_t)V_}, torch::kFloat32);
+    }
     auto weights = torch::zeros({batchsize}, torch::kFloat32);
     float* wacc = weights.data_ptr<float>();
     std::vector<int> ids(batchsize);
     auto take = [&](int i, int id) {
       evicted_[id] = false;  // getElementAndMark (:177-181)
-      std::memcpy(batch.query.data_ptr<float>() + (size_t)i * Q_, &q_[(size_t)id * Q_], sizeof(float) * Q_);
-      std::memcpy(batch.values.data_ptr<float>() + (size_t)i * V_, &v_[(size_t)id * V_], sizeof(float) * V_);
+      if (!on_host) return;  // device ring: one batched gather below, once every index is known
+      std::memcpy(batch.query.data_ptr<float>() + (size_t)i * Q_, tq.data_ptr<float>() + (size_t)id * Q_, sizeof(float) * Q_);
+      std::memcpy(batch.values.data_ptr<float>() + (size_t)i * V_, tv.data_ptr<float>() + (size_t)id * V_, sizeof(float) * V_);
     };
     if (use_priority_) {  // sample_with_priorities_ (:371-449): one draw per equal-mass segment
       const float segment = sum / batchsize;
@@ -374,6 +461,13 @@ class ValuePrioritizedReplay {
         take(i, id);
       }
     }
+    if (!on_host) {  // batched gather on the GPU that holds the ring; enqueued BEFORE any slot is released for reuse
+      auto idx = torch::empty({batchsize}, torch::kInt64);
+      for (int i = 0; i < batchsize; ++i) idx.data_ptr<int64_t>()[i] = ids[i];
+      idx = idx.to(tq.device());
+      batch.query = tq.index_select(0, idx);
+      batch.values = tv.index_select(0, idx);
+    }
     int full;
     {
       std::lock_guard<std::mutex> lk(m_);
@@ -386,10 +480,10 @@ class ValuePrioritizedReplay {
       weights = torch::pow(full * weights, -beta_);
       weights /= weights.max();
     }
-    if (device != "cpu") {
+    {
       const torch::Device d(device);
-      weights = use_priority_ ? weights.to(d) : weights;
-      batch.query = batch.query.to(d);
+      if (device != "cpu") weights = use_priority_ ? weights.to(d) : weights;
+      batch.query = batch.query.to(d);  // no-op when the ring already lives on the requested device
       batch.values = batch.values.to(d);
     }
     if (compressed_values_) batch.values = batch.values.to(torch::kFloat32) / 255;  // rela::dequantize
@@ -405,7 +499,8 @@ class ValuePrioritizedReplay {
   int head_ = 0, tail_ = 0, size_ = 0, safe_tail_ = 0, safe_size_ = 0;
   double sum_ = 0;
   int64_t Q_ = -1, V_ = -1;
-  std::vector<float> q_, v_, weights_;
+  torch::Tensor tq_, tv_;  // [ring][Q], [ring][V] f32, host memory or the producing GPU (ensure_layout)
+  std::vector<float> weights_;
   std::vector<bool> evicted_;
   std::atomic<int> num_add_{0};
   std::mutex m_sampler_;
@@ -544,7 +639,10 @@ class ModelLocker {
   }
 
   void update_model(py::object py_model) {  // model_locker.h:69-79
-    for (auto& m : py_models_) m.attr("load_state_dict")(py_model.attr("state_dict")());
+    {  // the reference blocks until every replica is idle (:71-75): no TorchScript forward may see torn weights
+      std::lock_guard<std::mutex> lj(jit_m_);
+      for (auto& m : py_models_) m.attr("load_state_dict")(py_model.attr("state_dict")());
+    }
     refresh_weights(py_models_[0]);
     std::lock_guard<std::mutex> lk(m_);
     for (rbl_engine* e : engines_) apply(e);
@@ -586,6 +684,7 @@ class ModelLocker {
 
   static void jit_forward(void* user, const float* q, int64_t rows, int64_t qs, float* out, int64_t n_out, void*) {
     auto* self = static_cast<ModelLocker*>(user);
+    std::lock_guard<std::mutex> lj(self->jit_m_);
     torch::NoGradGuard ng;
     const auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::kCUDA, self->device_index);
     auto qt = torch::from_blob(const_cast<float*>(q), {rows, qs}, opt);
@@ -606,7 +705,7 @@ class ModelLocker {
   }
 
   std::vector<py::object> py_models_;
-  std::mutex m_;
+  std::mutex m_, jit_m_;  // jit_m_: load_state_dict vs the generic TorchScript forward (never held together with m_)
   MlpHost mlp_;
   bool is_mlp_ = false;
   torch::jit::Module* jit_ = nullptr;
@@ -693,6 +792,7 @@ class Context {  // rela/context.h:26-85
   }
 
   void pause() {
+    check_workers();
     std::lock_guard<std::mutex> lk(m_pause_);
     paused_ = true;
   }
@@ -708,6 +808,7 @@ class Context {  // rela/context.h:26-85
     resume();
   }
   bool terminated() {
+    check_workers();
     int done = 0, total = 0;
     for (auto& w : workers_) {
       total += w->n_loops;
@@ -727,10 +828,19 @@ class Context {  // rela/context.h:26-85
     rbl_engine* engine = nullptr;
     rbl_selfplay* sp = nullptr;
     std::thread thread;
-    std::atomic<bool> done{false};
+    std::atomic<bool> done{false}, failed{false};
+    std::string error;  // written once by the worker before `failed` is set
     const std::atomic<bool>* stop = nullptr;
     std::vector<float> ones;
   };
+
+  // A generator that died (bad configuration surfacing late, a HIP error) must not look like a slow one: the next
+  // pause() / terminated() call from the training loop raises its error (the reference's threads would have crashed
+  // the process with an uncaught exception).
+  void check_workers() {
+    for (auto& w : workers_)
+      if (w->failed) fail("rebel_amd.rela: data generation stopped: " + w->error);
+  }
 
   static void sink(void* user, int64_t n, const int32_t*, const float* q, int64_t qs, const float* v, int64_t vs) {
     auto* w = static_cast<Worker*>(user);  // CVNetBufferConnector::add_training_example (rela/data_loop.h:50-55)
@@ -740,6 +850,7 @@ class Context {  // rela/context.h:26-85
 
   void run(Worker* w) {  // DataThreadLoop::mainLoop (rela/data_loop.h:67-76), all lanes of the engine at once
     w->stop = &stop_;
+    bool host_sink = std::getenv("REBEL_AMD_REPLAY_HOST") != nullptr;
     try {
       while (!stop_) {
         {
@@ -747,10 +858,26 @@ class Context {  // rela/context.h:26-85
           cv_pause_.wait(lk, [this] { return !paused_ || stop_; });
         }
         if (stop_) break;
-        if (rbl_selfplay_advance(w->sp, &Context::sink, w) < 0) fail(rbl_last_error());
+        // an engine whose walk runs on the device keeps the epoch's examples in GPU memory: block-append them to the
+        // replay's device ring (device-to-device) instead of reading them back
+        const bool dev = !host_sink && rbl_selfplay_on_device(w->sp) == 1;
+        const int64_t its = rbl_selfplay_advance(w->sp, dev ? nullptr : &Context::sink, dev ? nullptr : w);
+        if (its < 0) fail(rbl_last_error());
+        const float *dq = nullptr, *dv = nullptr;
+        if (dev) check(rbl_selfplay_device_examples(w->sp, &dq, &dv), "device_examples");
+        if (dev && dq) {
+          const int64_t n = 2 * (int64_t)w->seeds.size();
+          w->replay->add_block_device(dq, rbl_query_size(w->cfg.num_dice, w->cfg.num_faces), dv,
+                                      rbl_num_hands(w->cfg.num_dice, w->cfg.num_faces), n, w->locker->device_index,
+                                      w->stop);
+        } else if (dev) {
+          fail("internal: device examples requested from a host-walk engine");
+        }
       }
     } catch (const std::exception& ex) {
       std::fprintf(stderr, "rebel_amd.rela: generator stopped: %s\n", ex.what());
+      w->error = ex.what();
+      w->failed = true;
     }
     w->done = true;
   }
@@ -884,6 +1011,7 @@ PYBIND11_MODULE(rela, m) {
       .def("save", &ValuePrioritizedReplay::save)
       .def("extract", &ValuePrioritizedReplay::extract)
       .def("push", &ValuePrioritizedReplay::push, py::call_guard<py::gil_scoped_release>())
+      .def("_storage_device", &ValuePrioritizedReplay::storage_device)  // not in the reference: where the rings live
       .def("update_priority", &ValuePrioritizedReplay::update_priority);
 
   py::class_<ThreadLoop, std::shared_ptr<ThreadLoop>>(m, "ThreadLoop");

@@ -198,3 +198,75 @@ def test_eval_helpers_against_oracle(tmp_path, port):
     cfg2 = _cfg(rela, 1, 2, 180)
     total = rela.compute_exploitability_fp(cfg2)
     assert 0 <= total < 1e-3  # subgame_solving_test.cc:162-179
+
+
+def test_device_replay_ring_equals_host_ring(tmp_path):
+    """the same contents pushed as CUDA tensors (device ring, device-to-device block appends, batched
+    gather on the GPU) and as CPU tensors (host ring) -- same seed => identical batches, weights, eviction and files."""
+    import torch
+
+    import rebel_amd.rela as rela
+
+    rng = np.random.default_rng(0)
+    Q, V, cap = 27, 6, 600
+    for use_priority in (False, True):
+        host = rela.ValuePrioritizedReplay(capacity=cap, seed=7, alpha=0.8, beta=0.4, prefetch=0,
+                                           use_priority=use_priority, compressed_values=False)
+        dev = rela.ValuePrioritizedReplay(capacity=cap, seed=7, alpha=0.8, beta=0.4, prefetch=0,
+                                          use_priority=use_priority, compressed_values=False)
+        for rnd in range(4):  # 4 x 170 rows: wraps the 750-slot ring, sample() trims back to capacity in between
+            q = torch.from_numpy(rng.random((170, Q), np.float32))
+            v = torch.from_numpy(rng.random((170, V), np.float32))
+            w = torch.from_numpy(rng.uniform(0.5, 2.0, 170).astype(np.float32))
+            host.push([q, v, w])
+            dev.push([q.cuda(), v.cuda(), w])
+            assert host._storage_device() == "cpu" and dev._storage_device() == "cuda:0"
+            assert host.size() == dev.size()
+            for _ in range(3):
+                (bh, wh), (bd, wd) = host.sample(64, "cpu"), dev.sample(64, "cuda:0")
+                assert bd.query.device.type == "cuda" and bd.values.device.type == "cuda"
+                assert torch.equal(bh.query, bd.query.cpu()) and torch.equal(bh.values, bd.values.cpu())
+                assert torch.equal(wh, wd.cpu())
+                if use_priority:
+                    pr = torch.from_numpy(rng.uniform(0.1, 3.0, 64).astype(np.float32))
+                    host.update_priority(pr)
+                    dev.update_priority(pr)
+        fh, fd = str(tmp_path / f"h{use_priority}.bin"), str(tmp_path / f"d{use_priority}.bin")
+        host.save(fh)
+        dev.save(fd)
+        assert open(fh, "rb").read() == open(fd, "rb").read()  # rela/types.cc:87-111 byte format, same slots
+        eh, ed = host.extract(), dev.extract()
+        for a, b in zip(eh, ed):
+            assert torch.equal(a, b)
+
+
+def test_datagen_appends_to_the_device_ring_and_tiny_buffers_do_not_stall():
+    """Engines whose walk runs on the device block-append to the replay's device ring; an epoch (2 x 64 examples) larger
+    than what a full 40-slot buffer can admit at once is appended in chunks while the consumer samples (the
+    one-block append could wait forever)."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    torch.manual_seed(0)
+    net = Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2)
+    m = torch.jit.script(net.to("cuda:0")).eval()
+    locker = rela.ModelLocker([m], "cuda:0")
+    replay = rela.ValuePrioritizedReplay(capacity=40, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    ctx = rela.Context()
+    cfg = _cfg(rela, 1, 4, 8)
+    for i in range(64):
+        ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, i))
+    ctx.start()
+    _wait(lambda: replay.size() >= 40)
+    assert replay._storage_device() == "cuda:0"
+    n0 = replay.num_add()
+    t0 = time.time()
+    while replay.num_add() < n0 + 6 * 128:  # the consumer keeps sampling: six more epochs must get through
+        b, _ = replay.sample(16, "cuda:0")
+        assert b.query.shape == (16, 19) and torch.isfinite(b.values).all()
+        assert time.time() - t0 < 120, "producer stalled on a full buffer"
+    ctx.terminate()
+    _wait(ctx.terminated, 60)

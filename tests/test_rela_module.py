@@ -199,3 +199,34 @@ def test_eval_helpers_need_a_gpu(ours):
     p.subgame_params.use_cfr = True
     with pytest.raises(RuntimeError, match="HIP|device"):
         ours.compute_exploitability_fp(p)
+
+
+def test_blocks_larger_than_the_free_space_are_appended_in_chunks(ours):
+    """A block of 2 x lanes examples against a small buffer: the producer only ever asks for ring - capacity slots at a
+    time, which sample()'s trim always frees; contents arrive complete and in order."""
+    r = ours.ValuePrioritizedReplay(capacity=32, seed=3, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                    compressed_values=False)
+    n = 200  # five times the 40-slot ring
+    q = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+    v = torch.arange(n * 2, dtype=torch.float32).reshape(n, 2) + 0.5
+    seen = []
+    done = threading.Event()
+
+    def producer():
+        r.push([q, v, torch.ones(n)])
+        done.set()
+
+    th = threading.Thread(target=producer)
+    th.start()
+    t0 = time.time()
+    while not done.is_set():
+        if r.size() > 0:
+            b, _ = r.sample(4, "cpu")
+            seen.append(b.query[:, 0].clone())
+        assert time.time() - t0 < 60, "producer stalled"
+        time.sleep(0.001)
+    th.join()
+    assert r.num_add() == n
+    tail = r.extract()
+    assert torch.equal(tail[0], q[n - tail[0].shape[0]:]) and torch.equal(tail[1], v[n - tail[1].shape[0]:])
+    assert all((s % 3 == 0).all() for s in seen)  # every sampled row is a whole row of the source

@@ -19,7 +19,6 @@ def _run_lanes(c, seeds, games, expect_device=1):
     e = capi.Engine(c["d"], c["f"], capi.make_params(**c["p"]), max_lanes=len(seeds))
     e.set_net_synthetic() if c["net"] == "synthetic" else e.set_net_zero()
     sp = capi.SelfPlay(e, seeds, random_action_prob=c["rap"], sample_leaf=c["leaf"])
-    assert sp.on_device() == -1
     per_lane = [[] for _ in seeds]
     done_at = [None] * len(seeds)  # number of examples when the lane finished `games` games
     finished = [0] * len(seeds)
