@@ -756,12 +756,13 @@ class Context {  // rela/context.h:26-85
     return (int)lanes_.size();
   }
 
-  void start() {
-    if (started_) return;
-    started_ = true;
+  // The generator topology Context.start() will build (reference: one ModelLocker per generating GPU, threads_per_gpu
+  // threads each, cfvpy/selfplay.py:187-252): lanes that share a ModelLocker -- hence a device -- a replay and a
+  // configuration form ONE worker = one engine on that device + one driver thread.  Pure host logic.
+  void plan() {
+    if (!workers_.empty()) return;
     const char* lpt = std::getenv("REBEL_AMD_LANES_PER_THREAD");
     const int per = std::max(1, lpt && *lpt ? std::atoi(lpt) : 1);
-    // group lanes that can share an engine
     for (auto& lane : lanes_) {
       Worker* w = nullptr;
       for (auto& c : workers_)
@@ -776,6 +777,24 @@ class Context {  // rela/context.h:26-85
       for (int j = 0; j < per; ++j) w->seeds.push_back(lane->seed + j * 1000003);
       ++w->n_loops;
     }
+  }
+  // [(device string, device index, create_cfr_thread calls, lane seeds)] per worker -- introspection for tests / logs
+  std::vector<std::tuple<std::string, int, int, std::vector<int32_t>>> describe_plan() {
+    if (!started_) {
+      workers_.clear();
+      plan();
+    }
+    std::vector<std::tuple<std::string, int, int, std::vector<int32_t>>> out;
+    for (auto& w : workers_) out.emplace_back(w->locker->device, w->locker->device_index, w->n_loops, w->seeds);
+    if (!started_) workers_.clear();
+    return out;
+  }
+
+  void start() {
+    if (started_) return;
+    started_ = true;
+    workers_.clear();
+    plan();
     for (auto& w : workers_) {  // engines are created here so that configuration errors surface as Python exceptions
       const rbl_params p = to_c(w->cfg.subgame_params);
       w->engine = rbl_engine_create(w->locker->device_index, w->cfg.num_dice, w->cfg.num_faces, &p, (int)w->seeds.size());
@@ -1047,7 +1066,8 @@ PYBIND11_MODULE(rela, m) {
       .def("pause", &Context::pause)
       .def("resume", &Context::resume)
       .def("terminate", &Context::terminate)
-      .def("terminated", &Context::terminated);
+      .def("terminated", &Context::terminated)
+      .def("_plan", &Context::describe_plan);  // not in the reference: the worker / engine grouping start() builds
 
   py::class_<ModelLocker, std::shared_ptr<ModelLocker>>(m, "ModelLocker")
       .def(py::init<std::vector<py::object>, const std::string&>())

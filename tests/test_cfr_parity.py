@@ -130,13 +130,18 @@ def test_batched_heterogeneous_lanes_bit_exact(d, f, iters, port):
         assert np.array_equal(v, np.stack([x for _, x in o.examples]))
 
 
-def test_full_occupancy_lanes_bit_exact(port):
-    """4096 lanes (two streams, every CU holding its full complement of CFR workgroups next to the persistent net-free
-    path): a sample of lanes, spread over both halves, still equals its own oracle run bit for bit."""
+@pytest.mark.parametrize("d,f,iters,B,stride", [
+    (1, 6, 48, 4096, 173),     # two streams, every CU holding its full complement of CFR workgroups
+    (1, 4, 1024, 4096, 311),   # BASELINE config 2: 1dx4f, subgame_iters=1024, 4096 concurrent subgames
+    (2, 3, 1024, 1536, 257),   # BASELINE config 4: 2dx3f, subgame_iters=1024 (one GPU's lane set)
+    (2, 6, 96, 64, 13),        # BASELINE config 5's game: H = 36 lanes side by side on the big-tree kernel
+])
+def test_full_occupancy_lanes_bit_exact(port, d, f, iters, B, stride):
+    """Thousands of heterogeneous lanes in lock-step at the BASELINE configurations' sizes: a sample of lanes, spread over
+    both streams' halves, still equals its own oracle run bit for bit (state, snapshot at act_iteration, root values)."""
     from oracle import orc
     from rebel_amd import capi
 
-    d, f, iters, B = 1, 6, 48, 4096
     kw = dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
     A, H = port.num_actions(d, f), port.num_hands(d, f)
     rng = np.random.default_rng(99)
@@ -149,7 +154,7 @@ def test_full_occupancy_lanes_bit_exact(port):
     e.set_net_synthetic()
     e.reset(roots, players, beliefs, acts)
     e.multistep()
-    for b in list(range(0, B, 173)) + [B // 2 - 1, B // 2, B - 1]:
+    for b in list(range(0, B, stride)) + [B // 2 - 1, B // 2, B - 1]:
         o = port.solver(d, f, orc.make_params(**kw), int(roots[b]), int(players[b]), beliefs[b], orc.NET_SYNTHETIC)
         snap = None
         for it in range(iters):
@@ -283,3 +288,29 @@ def test_error_paths():
         e.reset([-1] * 3, [0] * 3, np.full((3, 2, e.H), 0.25))
     with pytest.raises(capi.RebelError):
         e.step(0)  # nothing was reset successfully
+
+
+def test_2d6f_root_2048_iterations_bit_exact(port):
+    """BASELINE config 5: 2 dice x 6 faces (H = 36, root subgame N = 325, L = 276), subgame_iters = 2048, next to three
+    smaller subgames of the same game: bit-exact against the oracle after 2048 iterations."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    d, f, iters = 2, 6, 2048
+    kw = dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+    H = port.num_hands(d, f)
+    rng = np.random.default_rng(5)
+    roots, players = [-1, 7, 16, 22], [0, 1, 0, 1]
+    beliefs = rng.dirichlet(np.ones(H), size=(4, 2))
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=4)
+    e.set_net_synthetic()
+    e.reset(roots, players, beliefs)
+    e.multistep()
+    for b in range(4):
+        o = port.solver(d, f, orc.make_params(**kw), roots[b], players[b], beliefs[b], orc.NET_SYNTHETIC)
+        o.multistep()
+        for w, ow in [(capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM), (capi.GET_REGRETS, orc.GET_REGRETS),
+                      (capi.GET_AVERAGE, orc.GET_AVERAGE)]:
+            assert np.array_equal(e.get(b, w), o.get(ow)), (b, w)
+        for pl in (0, 1):
+            assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))

@@ -230,3 +230,38 @@ def test_blocks_larger_than_the_free_space_are_appended_in_chunks(ours):
     tail = r.extract()
     assert torch.equal(tail[0], q[n - tail[0].shape[0]:]) and torch.equal(tail[1], v[n - tail[1].shape[0]:])
     assert all((s % 3 == 0).all() for s in seen)  # every sampled row is a whole row of the source
+
+
+def test_context_plans_one_engine_per_model_locker_device(ours, monkeypatch):
+    """The in-process multi-GPU topology (cfvpy/selfplay.py:187-252: one ModelLocker per generating GPU, threads_per_gpu
+    create_cfr_thread calls each, seeds rank*1000+i): Context.start() builds one worker = one engine + one driver thread
+    per (ModelLocker, replay, config) group, on the locker's device, holding exactly that group's lanes.  Host logic:
+    checked here without a GPU through the plan the context would start."""
+    from rebel_amd.models import Net2
+
+    m = [torch.jit.script(Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2)) for _ in range(3)]
+    lockers = [ours.ModelLocker([m[k]], f"cuda:{k + 1}") for k in range(3)]  # cuda:0 trains, cuda:1.. generate (:193)
+    replay = ours.ValuePrioritizedReplay(capacity=1024, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    cfg = ours.RecursiveSolvingParams()
+    cfg.num_dice, cfg.num_faces, cfg.random_action_prob, cfg.sample_leaf = 1, 4, 0.25, True
+    cfg.subgame_params.num_iters, cfg.subgame_params.use_cfr = 64, True
+    cfg2 = ours.RecursiveSolvingParams()
+    cfg2.num_dice, cfg2.num_faces, cfg2.random_action_prob, cfg2.sample_leaf = 1, 4, 0.25, True
+    cfg2.subgame_params.num_iters, cfg2.subgame_params.use_cfr = 128, True
+    ctx = ours.Context()
+    rank, per_gpu = 2, 5
+    seed = 0
+    for k, locker in enumerate(lockers):
+        for _ in range(per_gpu):
+            ctx.push_env_thread(ours.create_cfr_thread(locker, replay, cfg, rank * 1000 + seed))
+            seed += 1
+    ctx.push_env_thread(ours.create_cfr_thread(lockers[0], replay, cfg2, 7))  # other solver settings: its own engine
+    plan = ctx._plan()
+    assert [(dev, idx, n) for dev, idx, n, _ in plan] == [("cuda:1", 1, 5), ("cuda:2", 2, 5), ("cuda:3", 3, 5),
+                                                         ("cuda:1", 1, 1)]
+    assert [s for _, _, _, s in plan][:3] == [list(range(2000 + 5 * k, 2005 + 5 * k)) for k in range(3)]
+    assert plan[3][3] == [7]
+    monkeypatch.setenv("REBEL_AMD_LANES_PER_THREAD", "3")  # lanes per create_cfr_thread call, seed stride 1000003
+    plan = ctx._plan()
+    assert plan[0][2] == 5 and plan[0][3][:4] == [2000, 2000 + 1000003, 2000 + 2 * 1000003, 2001]
