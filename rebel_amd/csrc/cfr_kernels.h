@@ -82,5 +82,10 @@ void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_
 size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces);
 bool cfr_rows_supported(int H, int A, int dice, int faces);
 bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
+// the same kernel for lanes whose state does not fit LDS (2 dice x 6 faces): node values and reach rows in LDS, sigma /
+// regrets in place in global memory, 256 threads, one lane per CU
+size_t cfr_rows_global_lds_bytes(int N, int NI, int H, int faces);
+bool cfr_rows_global_supported(int H, int A, int dice, int faces);
+bool launch_cfr_rows_global(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream);
 
 }  // namespace rbl

@@ -43,8 +43,15 @@ __device__ __forceinline__ void store_row(double* p, const Row<H>& r) {
   for (int h = 0; h < H; ++h) p[h] = r.v[h];
 }
 
-template <int H, int A, int DICE, int FACES>
-__global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
+// GS ("global state"): for games whose per-lane state does not fit LDS (2 dice x 6 faces: H = 36, root tree N = 325, 93 KB
+// per strategy array) the kernel keeps only what is accessed irregularly -- node values [N][H], the reach rows of nodes
+// with children, the tree tables -- in LDS (124 KB at the root: one lane per CU) and works on sigma / regrets IN PLACE in
+// the lane's global slab: every element of them is touched a bounded number of times per step by the thread that owns
+// its row, in 16-byte pieces, and the rows of a lane sit in one contiguous stretch that stays in L2 for the whole step.
+// Leaf values are read from the net's output rows directly and query rows are written straight to the exchange buffer
+// by the pseudo-leaf's thread.  Same operations, same order: bit-exactness is unchanged.
+template <int H, int A, int DICE, int FACES, bool GS>
+__global__ void __launch_bounds__(GS ? 256 : 128) cfr_rows_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -56,8 +63,8 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   constexpr int kB = H % 2 == 0 ? 3 : (H <= 6 ? 5 : 7);         // strides of blockDim = 128 that cover the depth-2 root tree
   typedef double d2_t __attribute__((ext_vector_type(2)));
   typedef typename std::conditional<kW == 2, d2_t, double>::type dw;
-  dw s_[kB], r_[kB];
-  {
+  dw s_[GS ? 1 : kB], r_[GS ? 1 : kB];
+  if constexpr (!GS) {
     const size_t le = (size_t)lane * a.Emax * H;
     const int cap = a.Emax * H / kW;
     const dw* gs = reinterpret_cast<const dw*>(a.sigma + le);
@@ -81,22 +88,37 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   const int t = a.trav, opp = 1 - t;
 
   // ---- LDS layout (doubles): rho0, rho1, yrow [NI][H] | sig [E][H] | val [N][H] | reg [E][H] | leaf values | tables
+  // GS layout: rho0, rho1, yrow [NI][H] | val [N][H] | tables  (sigma, regrets, leaf values, query rows stay in global memory)
+  const size_t lane_e = (size_t)lane * a.Emax * H;
+  double* g_sig = a.sigma + lane_e;
+  double* g_reg = a.regrets + lane_e;
   double* rho0 = lds;
   double* rho1 = rho0 + NI * H;
   double* yrow = rho1 + NI * H;  // refined reciprocals of the regret-matching row sums (see the normalisation pass)
-  double* sig = yrow + NI * H;
-  double* val = sig + E * H;
-  double* reg = val + N * H;
-  float* lvals = reinterpret_cast<float*>(reg + E * H);
-  int* tb = reinterpret_cast<int*>(lvals + ((L * H + 3) & ~3));
+  double* sig;
+  double* val;
+  double* reg;
+  const float* lvals;
+  int* tb;
+  if constexpr (GS) {
+    sig = g_sig;
+    reg = g_reg;
+    val = yrow + NI * H;
+    lvals = a.values + (size_t)row_off * H;
+    tb = reinterpret_cast<int*>(val + N * H);
+  } else {
+    sig = yrow + NI * H;
+    val = sig + E * H;
+    reg = val + N * H;
+    float* lv = reinterpret_cast<float*>(reg + E * H);
+    lvals = lv;
+    tb = reinterpret_cast<int*>(lv + ((L * H + 3) & ~3));
+  }
   int* t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
   int* t_irank = tb + 5 * N, *t_lrow = tb + 6 * N;
   int8_t* t_match = reinterpret_cast<int8_t*>(tb + 7 * N);
   float* qstage = reinterpret_cast<float*>(val);  // [L][Q], aliases val + reg once both are dead (host checks the size)
 
-  const size_t lane_e = (size_t)lane * a.Emax * H;
-  double* g_sig = a.sigma + lane_e;
-  double* g_reg = a.regrets + lane_e;
   double* g_sum = a.sums + lane_e;
   const double* bel = a.beliefs + (size_t)lane * 2 * H;
   double* rmean = a.root_mean + (size_t)lane * 2 * H;
@@ -129,11 +151,11 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
     const int8_t tm = a.matches[min(tid, FACES * H - 1)];
     constexpr int kV = H <= 6 ? 4 : 5;  // strides that cover the root's L * H leaf values (396 / 594)
     float v_[kV];
-    if (LH > 0) {  // uniform
+    if (!GS && LH > 0) {  // uniform
 #pragma unroll
       for (int u = 0; u < kV; ++u) v_[u] = gv[min(tid + u * nthr, LH - 1)];
     }
-    {
+    if constexpr (!GS) {
       dw* lsig = reinterpret_cast<dw*>(sig);
       dw* lreg = reinterpret_cast<dw*>(reg);
       const dw* gs = reinterpret_cast<const dw*>(g_sig);
@@ -152,12 +174,15 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
         lreg[i] = gr[i];
       }
     }
+    if constexpr (!GS) {
+      float* lv = const_cast<float*>(lvals);
 #pragma unroll
-    for (int u = 0; u < kV; ++u) {
-      const int i = tid + u * nthr;
-      if (i < LH) lvals[i] = v_[u];
+      for (int u = 0; u < kV; ++u) {
+        const int i = tid + u * nthr;
+        if (i < LH) lv[i] = v_[u];
+      }
+      for (int i = tid + kV * nthr; i < LH; i += nthr) lv[i] = gv[i];
     }
-    for (int i = tid + kV * nthr; i < LH; i += nthr) lvals[i] = gv[i];
     if (tid < N) {
       t_parent[tid] = tp;
       t_act[tid] = ta;
@@ -422,8 +447,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
             x0 += rp.v[2 * h] * s.v[2 * h];
             x1 += rp.v[2 * h + 1] * s.v[2 * h + 1];
             gs[h] = d2{x0, x1};
-            gg[h] = d2{s.v[2 * h], s.v[2 * h + 1]};
-            gr[h] = d2{rg.v[2 * h], rg.v[2 * h + 1]};
+            if constexpr (!GS) {  // GS: sigma and regrets were updated in place
+              gg[h] = d2{s.v[2 * h], s.v[2 * h + 1]};
+              gr[h] = d2{rg.v[2 * h], rg.v[2 * h + 1]};
+            }
           }
         } else {
 #pragma unroll
@@ -432,8 +459,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
             x *= a.strat;
             x += rp.v[h] * s.v[h];
             g_sum[e + h] = x;
-            g_sig[e + h] = s.v[h];
-            g_reg[e + h] = rg.v[h];
+            if constexpr (!GS) {
+              g_sig[e + h] = s.v[h];
+              g_reg[e + h] = rg.v[h];
+            }
           }
         }
       }
@@ -473,10 +502,11 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
   // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123)
   if (a.next_trav >= 0 && L > 0) {
     __syncthreads();  // val / reg are dead from here on: their bytes stage the query rows
+    float* gq = a.queries + (size_t)row_off * Q;
     for (int n = tid; n < N; n += nthr) {  // a pseudo-leaf's thread writes its row (no look-up of the global leaf list)
       const int k = t_lrow[n];
       if (k < 0) continue;
-      float* q = qstage + k * Q;
+      float* q = (GS ? gq : qstage) + k * Q;
       // rm: reach of the player who acted at the parent (times sigma), rn: the other player's (copied); which of the two is
       // player 0 only decides WHERE in the row they are written (a per-thread offset, not a per-element register select)
       Row<H> rm, rn;
@@ -509,9 +539,10 @@ __global__ void __launch_bounds__(128) cfr_rows_kernel(const CfrArgs a) {
       norm_row(rm, sm, qm);
       norm_row(rn, sn, qn);
     }
-    __syncthreads();
-    float* gq = a.queries + (size_t)row_off * Q;
-    for (int i = tid; i < L * Q; i += nthr) gq[i] = qstage[i];
+    if constexpr (!GS) {
+      __syncthreads();
+      for (int i = tid; i < L * Q; i += nthr) gq[i] = qstage[i];
+    }
   }
   RBL_STAMP();  // 8: queries
 #undef RBL_STAMP
@@ -525,6 +556,27 @@ size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces) {
   return (b + 15) & ~(size_t)15;
 }
 
+size_t cfr_rows_global_lds_bytes(int N, int NI, int H, int faces) {
+  const size_t b = ((size_t)3 * NI * H + (size_t)N * H) * 8 + (size_t)7 * N * 4 + (size_t)faces * H;
+  return (b + 15) & ~(size_t)15;
+}
+
+bool cfr_rows_global_supported(int H, int A, int dice, int faces) { return H == 36 && A == 25 && dice == 2 && faces == 6; }
+
+bool launch_cfr_rows_global(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream) {
+  if (!(a.H == 36 && a.A == 25 && a.dice == 2)) return false;
+  auto kern = cfr_rows_kernel<36, 25, 2, 6, true>;
+  static bool attr_set = false;  // more than 64 KB of dynamic LDS has to be requested explicitly
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      (void)hipGetLastError();
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, stream, a);
+  return true;
+}
+
 bool cfr_rows_supported(int H, int A, int dice, int faces) {
   return (H == 6 && A == 13 && dice == 1 && faces == 6) || (H == 4 && A == 9 && dice == 1 && faces == 4) ||
          (H == 5 && A == 11 && dice == 1 && faces == 5) || (H == 9 && A == 13 && dice == 2 && faces == 3);
@@ -533,7 +585,7 @@ bool cfr_rows_supported(int H, int A, int dice, int faces) {
 bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream) {
 #define RBL_ROWS(H_, A_, D_, F_)                                                                              \
   do {                                                                                                        \
-    hipLaunchKernelGGL((cfr_rows_kernel<H_, A_, D_, F_>), dim3(B), dim3(block), lds_bytes, stream, a);        \
+    hipLaunchKernelGGL((cfr_rows_kernel<H_, A_, D_, F_, false>), dim3(B), dim3(block), lds_bytes, stream, a); \
     return true;                                                                                              \
   } while (0)
   if (a.H == 6 && a.A == 13 && a.dice == 1) RBL_ROWS(6, 13, 1, 6);

@@ -140,6 +140,12 @@ void Engine::construct() {
     if ((size_t)s.L * g_.query_size() * 4 > stage) rows_ok_ = false;
   }
   if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
+  // big games (2 dice x 6 faces): the row kernel with the strategy arrays in place in global memory
+  rows_global_lds_ = 0;
+  for (const ShapeDev& s : tabs_.shapes)
+    rows_global_lds_ = std::max(rows_global_lds_, cfr_rows_global_lds_bytes(s.N, s.NI, g_.H, g_.faces));
+  rows_global_ok_ = !use_lds_ && env_int("RBL_CFR_ROWS", 1) && cfr_rows_global_supported(g_.H, g_.A, g_.dice, g_.faces) &&
+                    rows_global_lds_ <= 160 * 1024;
   rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   cfr_dbg_ = env_int("RBL_CFR_DBG", 0) != 0;
@@ -582,7 +588,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     a.lane0 = l0;
     const bool is_step = mode == kModeStep || mode == kModeFpStep;
     if (is_step) time_begin(0, st);
-    if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
+    if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
+    } else if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
       launch_cfr(a, cnt, block_, lds_bytes_, st);
     if (is_step) time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
