@@ -1,0 +1,519 @@
+// rebel_amd/csrc/cfr_wave_kernel.hip -- CFR::step for the common games, ONE WAVEFRONT per lane, element-parallel.
+//
+// cfr_rows_kernel.hip gives every tree ROW (H hands of one node / edge) to a thread of a 128-thread workgroup.  PMC
+// (profiles/r01_pmc_summary.txt) showed it issue-bound at ~3 260 wave-instructions per lane and step: the sequential-
+// in-action sums of a level run on as many threads as the level has parents (12, or 1 at the root) while each of them
+// issues H fp64 operations per child, the second wave of a lane mostly executes loop control, and a step has ~15
+// workgroup barriers.  Here a lane is one wave and the unit of work is an ELEMENT (row, hand):
+//   * sums over the actions of a node run on one thread per (node, hand): the same 12-long sequential chains, but 6x
+//     more of them per instruction (root tree: 78 threads instead of 13);
+//   * regret update, regret matching, normalisation, new reach, strategy sums and the query rows are flat maps over
+//     the edge elements with compile-time H (index arithmetic = a multiply-shift and one table look-up);
+//   * only the per-leaf work that needs a whole reach row at once (scale sum, terminal match histogram) stays
+//     row-per-thread;
+//   * no workgroup barriers: the phases of a lane are ordered by the wave's own in-order LDS pipeline
+//     (wave-scope fences only keep the compiler from reordering);
+//   * regrets never enter LDS (they are read and written once, by the owning thread, straight from / to the lane's
+//     slab), and of a query row only what changes between iterations is rewritten (the traverser flag and the two
+//     normalised reach vectors; player id and last-bid one-hot were written when the solver was built).
+// Arithmetic is operation for operation that of cfr_rows_kernel.hip / cfr_kernels.hip (same operands, same order,
+// -ffp-contract=off, explicit fmas only where those kernels have them), so the bit-exactness contract with the reference
+// (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py and tests/test_selfplay_parity.py run against it.
+// Only kModeStep of LDS-resident lanes runs here (RBL_CFR_WAVE=0 switches back to the row kernel).
+#include "cfr_kernels.h"
+
+namespace rbl {
+
+namespace {
+
+constexpr double kEps = 1e-80;
+
+template <int H>
+struct Row {
+  double v[H];
+};
+template <int H>
+__device__ __forceinline__ Row<H> load_row(const double* p) {
+  Row<H> r;
+#pragma unroll
+  for (int h = 0; h < H; ++h) r.v[h] = p[h];
+  return r;
+}
+template <int H>
+__device__ __forceinline__ void store_row(double* p, const Row<H>& r) {
+#pragma unroll
+  for (int h = 0; h < H; ++h) p[h] = r.v[h];
+}
+
+// orders this wave's LDS / global accesses across a phase boundary: the LDS pipeline serves a wave's requests in
+// order, so no hardware barrier is needed -- only the compiler must not move accesses across
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ double refine_rcp(double s) {  // v_rcp_f64 + two Newton steps: the denominator part of `/`
+  double y = __builtin_amdgcn_rcp(s);
+  double e = __builtin_fma(-s, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-s, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double div_by(double num, double s, double y) {  // == num / s for 1e-80 <= num <= s (see rows kernel)
+  const double q0 = num * y;
+  const double rem = __builtin_fma(-s, q0, num);
+  return __builtin_fma(rem, y, q0);
+}
+
+// EHM / LHM / NM: upper bounds of E*H, L*H, N over the engine's shapes (fix the number of staging strides)
+template <int H, int A, int DICE, int FACES, int EHM, int LHM, int NM>
+__global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
+  constexpr int KS = (EHM + W - 1) / W, KV = (LHM + W - 1) / W, KN = (NM + W - 1) / W;
+  const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x;
+  typedef const int __attribute__((address_space(4)))* cint_p;
+  typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
+  const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
+  const int N = shc->N, E = N - 1, L = shc->L, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
+  const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
+  const int t = a.trav, opp = 1 - t;
+  const int EH = E * H, LH = L * H;
+
+  const size_t lane_e = (size_t)lane * a.Emax * H;
+  double* g_sig = a.sigma + lane_e;
+  double* g_reg = a.regrets + lane_e;
+  double* g_sum = a.sums + lane_e;
+  const double* bel = a.beliefs + (size_t)lane * 2 * H;
+  double* rmean = a.root_mean + (size_t)lane * 2 * H;
+  const bool snap_now = a.lane_act_iter && ((cint_p)a.lane_act_iter)[lane] == a.steps_after;
+
+  // ---- LDS layout
+  double* sig = lds;                 // [E][H]
+  double* val = sig + EH;            // [N][H]
+  double* rho0 = val + N * H;        // [NI][H]
+  double* rho1 = rho0 + NI * H;
+  double* ysum = rho1 + NI * H;      // [NI][H] regret-matching row sums
+  double* yrcp = ysum + NI * H;      // [NI][H] their refined reciprocals
+  float* lvals = reinterpret_cast<float*>(yrcp + NI * H);  // [L][H]
+  // tree tables as bytes: every entry is a node id, an action, a row index or -1, all < 128 for these games (NM <= 127)
+  int8_t* tb = reinterpret_cast<int8_t*>(lvals + ((LH + 3) & ~3));
+  int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
+  int8_t *t_irank = tb + 5 * N, *t_lrow = tb + 6 * N, *t_leaf = tb + 7 * N;  // t_leaf[k]: node of net row k
+  int8_t* t_match = t_leaf + L;
+
+  long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
+  int dbg_k = 0;
+#define RBL_STAMP()                                                 \
+  do {                                                              \
+    if (dbg && tid == 0) dbg[dbg_k] = (long long)clock64();         \
+    ++dbg_k;                                                        \
+  } while (0)
+  RBL_STAMP();  // 0
+
+  // ---------------------------------------------------------------- stage: every global load in flight before the first store
+  double bel_t = 0.0, rmean_t = 0.0;
+  {
+    double s_[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) s_[u] = g_sig[min(tid + u * W, EH - 1 < 0 ? 0 : EH - 1)];
+    const float* gv = a.values + (size_t)row_off * H;
+    float v_[KV];
+    if (LH > 0) {
+#pragma unroll
+      for (int u = 0; u < KV; ++u) v_[u] = gv[min(tid + u * W, LH - 1)];
+    }
+    const int* gp = a.parent + node_off;
+    const int* ga = a.act + node_off;
+    const int* gb = a.cb + node_off;
+    const int* ge = a.ce + node_off;
+    const int* gd = a.depth + node_off;
+    const int* gi = a.irank + node_off;
+    const int* gl = a.leaf_row + node_off;
+    const int* gk = a.leaves + shc->leaf_off;
+    int tp[KN], ta[KN], tcb[KN], tce[KN], td[KN], ti[KN], tl[KN], tk[KN];
+#pragma unroll
+    for (int u = 0; u < KN; ++u) {
+      const int nn = min(tid + u * W, N - 1);
+      tp[u] = gp[nn];
+      ta[u] = ga[nn];
+      tcb[u] = gb[nn];
+      tce[u] = ge[nn];
+      td[u] = gd[nn];
+      ti[u] = gi[nn];
+      tl[u] = gl[nn];
+      tk[u] = L > 0 ? gk[min(tid + u * W, L - 1)] : 0;
+    }
+    const int8_t tm = a.matches[min(tid, FACES * H - 1)];
+    if (tid < H) {
+      bel_t = bel[t * H + tid];
+      rmean_t = rmean[t * H + tid];
+      rho0[tid] = t == 0 ? bel_t : bel[tid];
+      rho1[tid] = t == 1 ? bel_t : bel[H + tid];
+    }
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int i = tid + u * W;
+      if (i < EH) sig[i] = s_[u];
+    }
+    for (int i = tid + KS * W; i < EH; i += W) sig[i] = g_sig[i];  // shapes beyond the template bounds (not expected)
+    if (LH > 0) {
+#pragma unroll
+      for (int u = 0; u < KV; ++u) {
+        const int i = tid + u * W;
+        if (i < LH) lvals[i] = v_[u];
+      }
+      for (int i = tid + KV * W; i < LH; i += W) lvals[i] = gv[i];
+    }
+#pragma unroll
+    for (int u = 0; u < KN; ++u) {
+      const int i = tid + u * W;
+      if (i < N) {
+        t_parent[i] = (int8_t)tp[u];
+        t_act[i] = (int8_t)ta[u];
+        t_cb[i] = (int8_t)tcb[u];
+        t_ce[i] = (int8_t)tce[u];
+        t_depth[i] = (int8_t)td[u];
+        t_irank[i] = (int8_t)ti[u];
+        t_lrow[i] = (int8_t)tl[u];
+      }
+      if (i < L) t_leaf[i] = (int8_t)tk[u];
+    }
+    static_assert(NM <= 127, "byte tables");
+    if (tid < FACES * H) t_match[tid] = tm;
+    for (int i = tid + W; i < FACES * H; i += W) t_match[i] = a.matches[i];
+  }
+  wave_sync();
+  RBL_STAMP();  // 1: staged
+
+  // value of a node without children from its opponent-reach row (query_value_net :257-268 / terminal payoffs :80-98):
+  // needs the whole row at once, so it stays row-per-thread (same code as cfr_rows_kernel.hip)
+  auto leaf_value = [&](int n, const Row<H>& ro) {
+    Row<H> out;
+    if (t_act[n] == A - 1) {
+      const int bid = t_act[t_parent[n]];
+      const int qty = 1 + bid / FACES, face = bid % FACES;
+      const int8_t* m = t_match + face * H;
+      double b[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) b[k] = 0.0;
+      double s = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mh = m[h];
+#pragma unroll
+        for (int k = 0; k <= DICE; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;
+        s += ro.v[h];
+      }
+#pragma unroll
+      for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];
+      const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
+      double cand[DICE + 1];
+#pragma unroll
+      for (int mm = 0; mm <= DICE; ++mm) {
+        const int left = max(0, qty - mm);
+        double bl = b[0];
+#pragma unroll
+        for (int k = 1; k < NB; ++k) bl = (left == k) ? b[k] : bl;
+        cand[mm] = (double)(float)bl * 2 - s;  // fp32 truncation (:785)
+        if (inverse) cand[mm] *= -1.0;
+      }
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const int mh = m[h];
+        double x = cand[0];
+#pragma unroll
+        for (int mm = 1; mm <= DICE; ++mm) x = (mh == mm) ? cand[mm] : x;
+        out.v[h] = x;
+      }
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) s += ro.v[h];
+      const float* lv = lvals + t_lrow[n] * H;
+#pragma unroll
+      for (int h = 0; h < H; ++h) out.v[h] = (double)(float)((double)lv[h] * s);
+    }
+    store_row<H>(val + n * H, out);
+  };
+
+  // ---------------------------------------------------------------- reach of both players under sigma, level by level; rows
+  // are stored for nodes with children, leaves turn theirs into a value right away
+  if (tid == 0 && t_cb[0] == t_ce[0]) leaf_value(0, load_row<H>(opp == 0 ? rho0 : rho1));
+  for (int lev = 1; lev < nlev; ++lev) {
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
+    const int mover = root_player ^ ((lev - 1) & 1);
+    double* rho_m = mover == 0 ? rho0 : rho1;
+    double* rho_n = mover == 0 ? rho1 : rho0;
+    for (int n = n0 + tid; n < n1; n += W) {
+      const int pr = t_irank[t_parent[n]];
+      const int ir = t_irank[n];
+      if (ir >= 0) {
+        Row<H> rm = load_row<H>(rho_m + pr * H);
+        const Row<H> rn = load_row<H>(rho_n + pr * H), s = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * s.v[h];
+        store_row<H>(rho_m + ir * H, rm);
+        store_row<H>(rho_n + ir * H, rn);
+      } else if (mover == opp) {
+        Row<H> ro = load_row<H>(rho_m + pr * H);
+        const Row<H> s = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+        for (int h = 0; h < H; ++h) ro.v[h] = ro.v[h] * s.v[h];
+        leaf_value(n, ro);
+      } else {
+        leaf_value(n, load_row<H>(rho_n + pr * H));
+      }
+    }
+    wave_sync();
+  }
+  RBL_STAMP();  // 2: reach + leaf values
+  RBL_STAMP();  // 3
+  RBL_STAMP();  // 4
+
+  // ---------------------------------------------------------------- bottom-up (update_regrets :542-574) fused with regret
+  // matching (:619-634) and the regret discount (:639-650); element-parallel
+  double* rho_t = t == 0 ? rho0 : rho1;
+  // Per-thread view of a traverser level's edge elements i = tid + 64 u (element = (child c, hand h) of the level below):
+  // its regret and strategy-sum values (requested from global memory up front), the LDS offsets of its parent's value /
+  // reach row.  The regret update, the normalisation and the strategy-sum update all walk this same element set, so the
+  // index arithmetic is done once.  Depth-2 subgames have exactly one traverser level; for deeper trees the arrays of
+  // the LAST processed (shallowest) one stay alive for the write-back and the others are redone there.
+  double rq[KS], gs_[KS];
+  int pv[KS], pr[KS];
+  int lev_kept = -1;
+  for (int lev = nlev - 2; lev >= 0; --lev) {
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
+    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
+    const bool mine = (root_player ^ (lev & 1)) == t;
+    const int nh = (n1 - n0) * H, ch = (c_hi - c_lo) * H;
+    if (mine) {
+      lev_kept = lev;
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        const int i = max(0, min(tid + u * W, ch - 1));
+        rq[u] = g_reg[(c_lo - 1) * H + i];
+        gs_[u] = g_sum[(c_lo - 1) * H + i];
+        const int p = t_parent[c_lo + i / H], h = i % H;
+        pv[u] = p * H + h;
+        pr[u] = t_irank[p] * H + h;
+      }
+    }
+    for (int i = tid; i < nh; i += W) {  // node value of (n, h): sequential over the actions, ascending
+      const int n = n0 + i / H, h = i % H;
+      const int c0 = t_cb[n], c1 = t_ce[n];
+      if (c0 == c1) continue;
+      // the additions stay sequential in ascending action order; the LDS reads of four actions are issued together
+      // (reads past the node's last child land in other rows of the lane's LDS image and are never added)
+      double x = 0.0;
+      const double* pv_ = val + c0 * H + h;
+      const double* ps_ = sig + (c0 - 1) * H + h;
+      if (mine) {
+        for (int c = c0; c < c1; c += 4, pv_ += 4 * H, ps_ += 4 * H) {
+          const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
+          const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
+          x += v0 * s0;
+          if (c + 1 < c1) x += v1 * s1;
+          if (c + 2 < c1) x += v2 * s2;
+          if (c + 3 < c1) x += v3 * s3;
+        }
+      } else {
+        for (int c = c0; c < c1; c += 4, pv_ += 4 * H) {
+          const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
+          x += v0;
+          if (c + 1 < c1) x += v1;
+          if (c + 2 < c1) x += v2;
+          if (c + 3 < c1) x += v3;
+        }
+      }
+      val[n * H + h] = x;
+    }
+    wave_sync();
+    if (!mine) continue;
+    double* lsig = sig + (c_lo - 1) * H;
+    double* greg = g_reg + (c_lo - 1) * H;
+    const double* lval = val + c_lo * H;
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {  // regret update + regret matching numerators, one thread per edge element
+      const int i = tid + u * W;
+      if (i < ch) {
+        double q = rq[u];
+        q += lval[i];
+        q -= val[pv[u]];
+        lsig[i] = q > kEps ? q : kEps;
+        greg[i] = q * (q > 0 ? a.pos : a.neg);
+      }
+    }
+    for (int i = tid + KS * W; i < ch; i += W) {  // levels wider than the template bound (not expected)
+      const int pp = t_parent[c_lo + i / H], h = i % H;
+      double q = greg[i];
+      q += lval[i];
+      q -= val[pp * H + h];
+      lsig[i] = q > kEps ? q : kEps;
+      greg[i] = q * (q > 0 ? a.pos : a.neg);
+    }
+    wave_sync();
+    for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions, and their refined reciprocals
+      const int n = n0 + i / H, h = i % H;
+      const int c0 = t_cb[n], c1 = t_ce[n];
+      if (c0 == c1) continue;
+      double s = 0.0;
+      const double* ps_ = sig + (c0 - 1) * H + h;
+      for (int c = c0; c < c1; c += 4, ps_ += 4 * H) {
+        const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
+        s += s0;
+        if (c + 1 < c1) s += s1;
+        if (c + 2 < c1) s += s2;
+        if (c + 3 < c1) s += s3;
+      }
+      const int ir = t_irank[n];
+      ysum[ir * H + h] = s;
+      yrcp[ir * H + h] = refine_rcp(s);
+    }
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < KS; ++u) {
+      const int i = tid + u * W;
+      if (i < ch) lsig[i] = div_by(lsig[i], ysum[pr[u]], yrcp[pr[u]]);
+    }
+    for (int i = tid + KS * W; i < ch; i += W) {
+      const int ir = t_irank[t_parent[c_lo + i / H]], h = i % H;
+      lsig[i] = div_by(lsig[i], ysum[ir * H + h], yrcp[ir * H + h]);
+    }
+    wave_sync();
+  }
+  RBL_STAMP();  // 5: bottom-up
+
+  // ---------------------------------------------------------------- running mean of the root values (:579-590)
+  if (tid < H) {
+    double m = rmean_t;
+    m += (val[tid] - m) * a.alpha;
+    rmean[t * H + tid] = m;
+  }
+  // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638), rows of
+  // nodes with children only (the root row still holds the traverser's beliefs)
+  for (int lev = 1; lev < nlev - 1; ++lev) {
+    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
+    const bool own = (root_player ^ ((lev - 1) & 1)) == t;
+    const int nh = (n1 - n0) * H;
+    for (int i = tid; i < nh; i += W) {
+      const int n = n0 + i / H, h = i % H;
+      const int ir = t_irank[n];
+      if (ir < 0) continue;
+      double r = rho_t[t_irank[t_parent[n]] * H + h];
+      if (own) r = r * sig[(n - 1) * H + h];
+      rho_t[ir * H + h] = r;
+    }
+    wave_sync();
+  }
+  RBL_STAMP();  // 6: new reach
+
+  // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed:
+  // the traverser's levels only (contiguous edge ranges), from the per-thread view built in the bottom-up sweep
+  for (int lev = 0; lev < nlev - 1; ++lev) {
+    if ((root_player ^ (lev & 1)) != t) continue;
+    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
+    const int ch = (c_hi - c_lo) * H, e0 = (c_lo - 1) * H;
+    if (lev == lev_kept) {
+#pragma unroll
+      for (int u = 0; u < KS; ++u) {
+        const int i = tid + u * W;
+        if (i < ch) {
+          const double sg = sig[e0 + i];
+          double x = gs_[u];
+          x *= a.strat;
+          x += rho_t[pr[u]] * sg;
+          g_sum[e0 + i] = x;
+          g_sig[e0 + i] = sg;
+        }
+      }
+    }
+    for (int i = tid + (lev == lev_kept ? KS * W : 0); i < ch; i += W) {
+      const int ir = t_irank[t_parent[c_lo + i / H]], h = i % H;
+      const double sg = sig[e0 + i];
+      double x = g_sum[e0 + i];
+      x *= a.strat;
+      x += rho_t[ir * H + h] * sg;
+      g_sum[e0 + i] = x;
+      g_sig[e0 + i] = sg;
+    }
+  }
+  if (snap_now) {
+    double* snap = a.snapshot + lane_e;
+    for (int i = tid; i < EH; i += W) snap[i] = sig[i];
+  }
+  RBL_STAMP();  // 7: write-back
+
+  // ---------------------------------------------------------------- queries for the next step (:253-269, :104-123): the
+  // traverser flag and the two normalised reach vectors of every pseudo-leaf row
+  if (a.next_trav >= 0 && L > 0) {
+    wave_sync();  // the traverser's reach rows were rewritten above
+    // One thread per (pseudo-leaf, player): that player's reach row at the leaf = the parent's row (times the new sigma
+    // where the player acted at the parent), normalised (normalize_probabilities_safe, util.h:68-78) and written as H
+    // floats into the leaf's query row.  The opponent's rows still hold the reach under the sigma of this step's start
+    // (it did not change), the traverser's were just recomputed: together the current strategy profile's reach.
+    float* gq = a.queries + (size_t)row_off * Q;
+    const float trav_flag = (float)a.next_trav;
+    for (int j = tid; j < 2 * L; j += W) {
+      const int k = j >> 1, pl = j & 1, n = t_leaf[k];
+      const double* rbase = pl == 0 ? rho0 : rho1;
+      Row<H> r;
+      const int ir = t_irank[n];
+      if (ir >= 0) {  // only the root can be a pseudo-leaf with a stored row (max_depth = 0)
+        r = load_row<H>(rbase + ir * H);
+      } else {
+        const int p = t_parent[n];
+        r = load_row<H>(rbase + t_irank[p] * H);
+        if ((root_player ^ (t_depth[p] & 1)) == pl) {
+          const Row<H> sg = load_row<H>(sig + (n - 1) * H);
+#pragma unroll
+          for (int h = 0; h < H; ++h) r.v[h] = r.v[h] * sg.v[h];
+        }
+      }
+      double ssum = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) ssum += r.v[h] + kEps;
+      const double y = refine_rcp(ssum);
+      float* q = gq + k * Q + 2 + A + pl * H;
+#pragma unroll
+      for (int h = 0; h < H; ++h) q[h] = (float)div_by(r.v[h] + kEps, ssum, y);
+      if (pl == 0) gq[k * Q + 1] = trav_flag;
+    }
+  }
+  RBL_STAMP();  // 8: queries
+#undef RBL_STAMP
+}
+
+}  // namespace
+
+size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int faces) {
+  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)4 * NI * H;  // doubles
+  const size_t b = d * 8 + (size_t)((L * H + 3) & ~3) * 4 + (size_t)(7 * N + L) + (size_t)faces * H;
+  return (b + 15) & ~(size_t)15;
+}
+
+// the instantiations cover depth-2 subgames of the game (max E*H, L*H, N over the shapes)
+bool cfr_wave_supported(int H, int A, int dice, int faces, int max_EH, int max_LH, int max_N) {
+  if (H == 6 && A == 13 && dice == 1 && faces == 6) return max_EH <= 540 && max_LH <= 396 && max_N <= 91;
+  if (H == 4 && A == 9 && dice == 1 && faces == 4) return max_EH <= 176 && max_LH <= 112 && max_N <= 45;
+  if (H == 5 && A == 11 && dice == 1 && faces == 5) return max_EH <= 325 && max_LH <= 225 && max_N <= 66;
+  if (H == 9 && A == 13 && dice == 2 && faces == 3) return max_EH <= 810 && max_LH <= 594 && max_N <= 91;
+  return false;
+}
+
+bool launch_cfr_wave(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream) {
+#define RBL_WAVE(H_, A_, D_, F_, EH_, LH_, N_)                                                                       \
+  do {                                                                                                               \
+    hipLaunchKernelGGL((cfr_wave_kernel<H_, A_, D_, F_, EH_, LH_, N_>), dim3(B), dim3(64), lds_bytes, stream, a);    \
+    return true;                                                                                                     \
+  } while (0)
+  if (a.H == 6 && a.A == 13 && a.dice == 1) RBL_WAVE(6, 13, 1, 6, 540, 396, 91);
+  if (a.H == 4 && a.A == 9 && a.dice == 1) RBL_WAVE(4, 9, 1, 4, 176, 112, 45);
+  if (a.H == 5 && a.A == 11 && a.dice == 1) RBL_WAVE(5, 11, 1, 5, 325, 225, 66);
+  if (a.H == 9 && a.A == 13 && a.dice == 2) RBL_WAVE(9, 13, 2, 3, 810, 594, 91);
+#undef RBL_WAVE
+  return false;
+}
+
+}  // namespace rbl

@@ -192,6 +192,8 @@ class Engine {
   bool rows_ok_ = false;  // kModeStep runs on cfr_rows_kernel (one thread per tree row)
   int rows_block_ = 128;
   size_t rows_lds_bytes_ = 0;
+  bool wave_ok_ = false;  // kModeStep runs on cfr_wave_kernel (one wavefront per lane)
+  size_t wave_lds_bytes_ = 0;
   bool rows_global_ok_ = false;  // big games: row kernel with sigma / regrets in place in global memory
   size_t rows_global_lds_ = 0;
   size_t part_rows_lds_[4] = {0, 0, 0, 0};  // per part: LDS of the largest tree among its lanes (set by reset)

@@ -140,6 +140,17 @@ void Engine::construct() {
     if ((size_t)s.L * g_.query_size() * 4 > stage) rows_ok_ = false;
   }
   if (rows_lds_bytes_ > std::min<size_t>(lds_cap, 64 * 1024)) rows_ok_ = false;
+  {  // one wavefront per lane, element-parallel (cfr_wave_kernel.hip): the default where it has an instantiation
+    int max_eh = 0, max_lh = 0;
+    wave_lds_bytes_ = 0;
+    for (const ShapeDev& s : tabs_.shapes) {
+      max_eh = std::max(max_eh, (s.N - 1) * g_.H);
+      max_lh = std::max(max_lh, s.L * g_.H);
+      wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, g_.faces));
+    }
+    wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 &&
+               cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
+  }
   // big games (2 dice x 6 faces): the row kernel with the strategy arrays in place in global memory
   rows_global_lds_ = 0;
   for (const ShapeDev& s : tabs_.shapes)
@@ -588,7 +599,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     a.lane0 = l0;
     const bool is_step = mode == kModeStep || mode == kModeFpStep;
     if (is_step) time_begin(0, st);
-    if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
+    if (mode == kModeStep && wave_ok_ && launch_cfr_wave(a, cnt, wave_lds_bytes_, st)) {
+    } else if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
     } else if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
       launch_cfr(a, cnt, block_, lds_bytes_, st);
     if (is_step) time_end(0, st);

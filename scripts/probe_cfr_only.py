@@ -1,6 +1,6 @@
 """Runs only CFR steps (synthetic elementwise net) on 4096 root lanes -- for rocprofv3 PMC runs of cfr_step_kernel."""
 import sys, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rebel_amd import capi
 B = 4096
 e = capi.Engine(1, 6, capi.make_params(num_iters=1024, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
