@@ -83,7 +83,10 @@ size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces);
 bool cfr_rows_supported(int H, int A, int dice, int faces);
 bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
 // cfr_wave_kernel.hip: kModeStep with ONE wavefront per lane, element-parallel (the default for the common games)
-size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int faces);
+// its staging loads are unconditional: every global array it reads must be padded by this many ELEMENTS behind the last
+// one a lane owns (sigma / values / the per-node and leaf tables / the match table)
+constexpr size_t kWavePad = 2048;
+size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces);
 bool cfr_wave_supported(int H, int A, int dice, int faces, int max_EH, int max_LH, int max_N);
 bool launch_cfr_wave(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream);
 // the same kernel for lanes whose state does not fit LDS (2 dice x 6 faces): node values and reach rows in LDS, sigma /

@@ -27,6 +27,7 @@ namespace rbl {
 namespace {
 
 constexpr double kEps = 1e-80;
+constexpr size_t kWaveLdsSlack = 256;  // bytes behind the lane's LDS image that the unconditional staging stores may touch
 
 template <int H>
 struct Row {
@@ -71,12 +72,12 @@ template <int H, int A, int DICE, int FACES, int EHM, int LHM, int NM>
 __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
-  constexpr int KS = (EHM + W - 1) / W, KV = (LHM + W - 1) / W, KN = (NM + W - 1) / W;
+  constexpr int KS = (EHM + W - 1) / W, KN = (NM + W - 1) / W;
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x;
   typedef const int __attribute__((address_space(4)))* cint_p;
   typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
   const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
-  const int N = shc->N, E = N - 1, L = shc->L, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
+  const int N = shc->N, E = N - 1, L = shc->L, T = shc->T, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
   const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
   const int t = a.trav, opp = 1 - t;
   const int EH = E * H, LH = L * H;
@@ -96,12 +97,11 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   double* rho1 = rho0 + NI * H;
   double* ysum = rho1 + NI * H;      // [NI][H] regret-matching row sums
   double* yrcp = ysum + NI * H;      // [NI][H] their refined reciprocals
-  float* lvals = reinterpret_cast<float*>(yrcp + NI * H);  // [L][H]
   // tree tables as bytes: every entry is a node id, an action, a row index or -1, all < 128 for these games (NM <= 127)
-  int8_t* tb = reinterpret_cast<int8_t*>(lvals + ((LH + 3) & ~3));
+  int8_t* tb = reinterpret_cast<int8_t*>(yrcp + NI * H);
   int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
-  int8_t *t_irank = tb + 5 * N, *t_lrow = tb + 6 * N, *t_leaf = tb + 7 * N;  // t_leaf[k]: node of net row k
-  int8_t* t_match = t_leaf + L;
+  int8_t *t_irank = tb + 5 * N, *t_leaf = tb + 6 * N, *t_term = t_leaf + L;  // t_leaf[k]: node of net row k; t_term[j]: j-th terminal
+  int8_t* t_match = t_term + T;
 
   long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
   int dbg_k = 0;
@@ -112,162 +112,167 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   } while (0)
   RBL_STAMP();  // 0
 
-  // ---------------------------------------------------------------- stage: every global load in flight before the first store
+  // ---------------------------------------------------------------- stage: every global load in flight before the first store.
+  // Loads and LDS stores are UNCONDITIONAL, at compile-time offsets from one per-thread base (no clamps, no exec-mask
+  // branches -- they were a third of this kernel's scalar instructions): the engine pads every global array these loads
+  // can overrun (kWavePad), and the LDS stores run front to back through the lane's image -- sigma, root reach rows,
+  // leaf values, the byte tables in layout order -- so whatever a too-long store spills into the following arrays is
+  // overwritten by the stores that own them (the LDS pipeline keeps a wave's stores in order); the image is allocated
+  // with kWaveLdsSlack bytes behind the last table for the final overrun.
   double bel_t = 0.0, rmean_t = 0.0;
+  // leaf values of net rows k = tid + 64 u, read by the thread that turns them into node values (unconditional loads:
+  // the values buffer is padded)
+  constexpr int KL = (LHM / H + W - 1) / W;
+  float lv_[KL][H];
+  {
+    const float* gv = a.values + ((size_t)row_off + tid) * H;
+#pragma unroll
+    for (int u = 0; u < KL; ++u)
+#pragma unroll
+      for (int h = 0; h < H; ++h) lv_[u][h] = gv[(size_t)u * W * H + h];
+  }
   {
     double s_[KS];
+    const double* gs0 = g_sig + tid;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) s_[u] = g_sig[min(tid + u * W, EH - 1 < 0 ? 0 : EH - 1)];
-    const float* gv = a.values + (size_t)row_off * H;
-    float v_[KV];
-    if (LH > 0) {
-#pragma unroll
-      for (int u = 0; u < KV; ++u) v_[u] = gv[min(tid + u * W, LH - 1)];
-    }
-    const int* gp = a.parent + node_off;
-    const int* ga = a.act + node_off;
-    const int* gb = a.cb + node_off;
-    const int* ge = a.ce + node_off;
-    const int* gd = a.depth + node_off;
-    const int* gi = a.irank + node_off;
-    const int* gl = a.leaf_row + node_off;
-    const int* gk = a.leaves + shc->leaf_off;
+    for (int u = 0; u < KS; ++u) s_[u] = gs0[u * W];
+    // (the net's output rows go straight into the registers of the thread that will consume them: lv_ below)
+    const int* gp = a.parent + node_off + tid;
+    const int* ga = a.act + node_off + tid;
+    const int* gb = a.cb + node_off + tid;
+    const int* ge = a.ce + node_off + tid;
+    const int* gd = a.depth + node_off + tid;
+    const int* gi = a.irank + node_off + tid;
+    const int* gl = a.terms + shc->term_off + tid;
+    const int* gk = a.leaves + shc->leaf_off + tid;
     int tp[KN], ta[KN], tcb[KN], tce[KN], td[KN], ti[KN], tl[KN], tk[KN];
 #pragma unroll
     for (int u = 0; u < KN; ++u) {
-      const int nn = min(tid + u * W, N - 1);
-      tp[u] = gp[nn];
-      ta[u] = ga[nn];
-      tcb[u] = gb[nn];
-      tce[u] = ge[nn];
-      td[u] = gd[nn];
-      ti[u] = gi[nn];
-      tl[u] = gl[nn];
-      tk[u] = L > 0 ? gk[min(tid + u * W, L - 1)] : 0;
+      tp[u] = gp[u * W];
+      ta[u] = ga[u * W];
+      tcb[u] = gb[u * W];
+      tce[u] = ge[u * W];
+      td[u] = gd[u * W];
+      ti[u] = gi[u * W];
+      tl[u] = gl[u * W];
+      tk[u] = gk[u * W];
     }
-    const int8_t tm = a.matches[min(tid, FACES * H - 1)];
+    const int8_t tm = a.matches[tid];
     if (tid < H) {
       bel_t = bel[t * H + tid];
       rmean_t = rmean[t * H + tid];
-      rho0[tid] = t == 0 ? bel_t : bel[tid];
-      rho1[tid] = t == 1 ? bel_t : bel[H + tid];
     }
+    const double b0 = tid < H ? (t == 0 ? bel_t : bel[tid]) : 0.0, b1 = tid < H ? (t == 1 ? bel_t : bel[H + tid]) : 0.0;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {
-      const int i = tid + u * W;
-      if (i < EH) sig[i] = s_[u];
+    for (int u = 0; u < KS; ++u) sig[tid + u * W] = s_[u];
+    if (tid < H) {
+      rho0[tid] = b0;
+      rho1[tid] = b1;
     }
-    for (int i = tid + KS * W; i < EH; i += W) sig[i] = g_sig[i];  // shapes beyond the template bounds (not expected)
-    if (LH > 0) {
+    int8_t* const tabs[8] = {t_parent, t_act, t_cb, t_ce, t_depth, t_irank, t_leaf, t_term};
+    const int* const regs[8] = {tp, ta, tcb, tce, td, ti, tk, tl};
 #pragma unroll
-      for (int u = 0; u < KV; ++u) {
-        const int i = tid + u * W;
-        if (i < LH) lvals[i] = v_[u];
-      }
-      for (int i = tid + KV * W; i < LH; i += W) lvals[i] = gv[i];
-    }
+    for (int k = 0; k < 8; ++k)
 #pragma unroll
-    for (int u = 0; u < KN; ++u) {
-      const int i = tid + u * W;
-      if (i < N) {
-        t_parent[i] = (int8_t)tp[u];
-        t_act[i] = (int8_t)ta[u];
-        t_cb[i] = (int8_t)tcb[u];
-        t_ce[i] = (int8_t)tce[u];
-        t_depth[i] = (int8_t)td[u];
-        t_irank[i] = (int8_t)ti[u];
-        t_lrow[i] = (int8_t)tl[u];
-      }
-      if (i < L) t_leaf[i] = (int8_t)tk[u];
-    }
+      for (int u = 0; u < KN; ++u) tabs[k][tid + u * W] = (int8_t)regs[k][u];
     static_assert(NM <= 127, "byte tables");
-    if (tid < FACES * H) t_match[tid] = tm;
-    for (int i = tid + W; i < FACES * H; i += W) t_match[i] = a.matches[i];
+    static_assert(FACES * H <= W, "match table staged by one store");
+    t_match[tid] = tm;
   }
   wave_sync();
   RBL_STAMP();  // 1: staged
 
-  // value of a node without children from its opponent-reach row (query_value_net :257-268 / terminal payoffs :80-98):
-  // needs the whole row at once, so it stays row-per-thread (same code as cfr_rows_kernel.hip)
-  auto leaf_value = [&](int n, const Row<H>& ro) {
-    Row<H> out;
-    if (t_act[n] == A - 1) {
-      const int bid = t_act[t_parent[n]];
-      const int qty = 1 + bid / FACES, face = bid % FACES;
-      const int8_t* m = t_match + face * H;
-      double b[NB];
+  // ---------------------------------------------------------------- reach of both players under sigma (:54-78) and the values
+  // of the nodes without children (query_value_net :257-268, terminal payoffs :80-98).  Three uniform passes instead of
+  // one per level with a three-way branch per node (pseudo-leaves and liar-call terminals alternate in node order, so a
+  // wave ran every branch for every node): reach rows of the nodes WITH children, level by level; then every
+  // pseudo-leaf (its net row order is the leaf list); then every terminal.  A childless node's value needs its whole
+  // opponent-reach row at once (scale sum / match histogram): those two passes are row-per-thread.
+  auto opp_reach_row = [&](int n) {  // opponent's reach at childless node n: the parent's row, times sigma if the opponent acted
+    const int p = t_parent[n];
+    Row<H> ro = load_row<H>((opp == 0 ? rho0 : rho1) + t_irank[p] * H);
+    if ((root_player ^ (t_depth[p] & 1)) == opp) {
+      const Row<H> sg = load_row<H>(sig + (n - 1) * H);
 #pragma unroll
-      for (int k = 0; k < NB; ++k) b[k] = 0.0;
-      double s = 0.0;
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const int mh = m[h];
-#pragma unroll
-        for (int k = 0; k <= DICE; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;
-        s += ro.v[h];
-      }
-#pragma unroll
-      for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];
-      const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
-      double cand[DICE + 1];
-#pragma unroll
-      for (int mm = 0; mm <= DICE; ++mm) {
-        const int left = max(0, qty - mm);
-        double bl = b[0];
-#pragma unroll
-        for (int k = 1; k < NB; ++k) bl = (left == k) ? b[k] : bl;
-        cand[mm] = (double)(float)bl * 2 - s;  // fp32 truncation (:785)
-        if (inverse) cand[mm] *= -1.0;
-      }
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const int mh = m[h];
-        double x = cand[0];
-#pragma unroll
-        for (int mm = 1; mm <= DICE; ++mm) x = (mh == mm) ? cand[mm] : x;
-        out.v[h] = x;
-      }
-    } else {
-      double s = 0.0;
-#pragma unroll
-      for (int h = 0; h < H; ++h) s += ro.v[h];
-      const float* lv = lvals + t_lrow[n] * H;
-#pragma unroll
-      for (int h = 0; h < H; ++h) out.v[h] = (double)(float)((double)lv[h] * s);
+      for (int h = 0; h < H; ++h) ro.v[h] = ro.v[h] * sg.v[h];
     }
-    store_row<H>(val + n * H, out);
+    return ro;
   };
-
-  // ---------------------------------------------------------------- reach of both players under sigma, level by level; rows
-  // are stored for nodes with children, leaves turn theirs into a value right away
-  if (tid == 0 && t_cb[0] == t_ce[0]) leaf_value(0, load_row<H>(opp == 0 ? rho0 : rho1));
-  for (int lev = 1; lev < nlev; ++lev) {
+  for (int lev = 1; lev < nlev - 1; ++lev) {
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const int mover = root_player ^ ((lev - 1) & 1);
     double* rho_m = mover == 0 ? rho0 : rho1;
     double* rho_n = mover == 0 ? rho1 : rho0;
     for (int n = n0 + tid; n < n1; n += W) {
-      const int pr = t_irank[t_parent[n]];
       const int ir = t_irank[n];
-      if (ir >= 0) {
-        Row<H> rm = load_row<H>(rho_m + pr * H);
-        const Row<H> rn = load_row<H>(rho_n + pr * H), s = load_row<H>(sig + (n - 1) * H);
+      if (ir < 0) continue;
+      const int pr = t_irank[t_parent[n]];
+      Row<H> rm = load_row<H>(rho_m + pr * H);
+      const Row<H> rn = load_row<H>(rho_n + pr * H), sg = load_row<H>(sig + (n - 1) * H);
 #pragma unroll
-        for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * s.v[h];
-        store_row<H>(rho_m + ir * H, rm);
-        store_row<H>(rho_n + ir * H, rn);
-      } else if (mover == opp) {
-        Row<H> ro = load_row<H>(rho_m + pr * H);
-        const Row<H> s = load_row<H>(sig + (n - 1) * H);
-#pragma unroll
-        for (int h = 0; h < H; ++h) ro.v[h] = ro.v[h] * s.v[h];
-        leaf_value(n, ro);
-      } else {
-        leaf_value(n, load_row<H>(rho_n + pr * H));
-      }
+      for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * sg.v[h];
+      store_row<H>(rho_m + ir * H, rm);
+      store_row<H>(rho_n + ir * H, rn);
     }
     wave_sync();
   }
+#pragma unroll
+  for (int u = 0; u < KL; ++u) {  // pseudo-leaves: net output row k, scaled by the opponent's total reach (:257-268)
+    const int k = tid + u * W;
+    if (k < L) {
+      const int n = t_leaf[k];
+      const Row<H> ro = n == 0 ? load_row<H>(opp == 0 ? rho0 : rho1) : opp_reach_row(n);
+      double ssum = 0.0;
+#pragma unroll
+      for (int h = 0; h < H; ++h) ssum += ro.v[h];
+      Row<H> out;
+#pragma unroll
+      for (int h = 0; h < H; ++h) out.v[h] = (double)(float)((double)lv_[u][h] * ssum);
+      store_row<H>(val + n * H, out);
+    }
+  }
+  for (int j = tid; j < T; j += W) {  // terminals: the bid that was called is the parent's last bid (:80-98, :765-789)
+    const int n = t_term[j];
+    const Row<H> ro = n == 0 ? load_row<H>(opp == 0 ? rho0 : rho1) : opp_reach_row(n);
+    const int bid = n == 0 ? 0 : t_act[t_parent[n]];
+    const int qty = 1 + bid / FACES, face = bid % FACES;
+    const int8_t* m = t_match + face * H;
+    double b[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) b[k] = 0.0;
+    double ssum = 0.0;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {  // b[m[h]] += r, without dynamic register indexing (x + 0.0 == x for x >= +0)
+      const int mh = m[h];
+#pragma unroll
+      for (int k = 0; k <= DICE; ++k) b[k] += (mh == k) ? ro.v[h] : 0.0;  // one hand shows at most DICE matches
+      ssum += ro.v[h];
+    }
+#pragma unroll
+    for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];  // bins above DICE are +0.0: adding them changes no bit
+    const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
+    double cand[DICE + 1];
+#pragma unroll
+    for (int mm = 0; mm <= DICE; ++mm) {
+      const int left = max(0, qty - mm);
+      double bl = b[0];
+#pragma unroll
+      for (int k = 1; k < NB; ++k) bl = (left == k) ? b[k] : bl;
+      cand[mm] = (double)(float)bl * 2 - ssum;  // fp32 truncation (:785)
+      if (inverse) cand[mm] *= -1.0;
+    }
+    Row<H> out;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const int mh = m[h];
+      double x = cand[0];
+#pragma unroll
+      for (int mm = 1; mm <= DICE; ++mm) x = (mh == mm) ? cand[mm] : x;
+      out.v[h] = x;
+    }
+    store_row<H>(val + n * H, out);
+  }
+  wave_sync();
   RBL_STAMP();  // 2: reach + leaf values
   RBL_STAMP();  // 3
   RBL_STAMP();  // 4
@@ -487,10 +492,10 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 
 }  // namespace
 
-size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int faces) {
+size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
   const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)4 * NI * H;  // doubles
-  const size_t b = d * 8 + (size_t)((L * H + 3) & ~3) * 4 + (size_t)(7 * N + L) + (size_t)faces * H;
-  return (b + 15) & ~(size_t)15;
+  const size_t b = d * 8 + (size_t)(6 * N + L + T) + (size_t)faces * H;
+  return ((b + 15) & ~(size_t)15) + kWaveLdsSlack;
 }
 
 // the instantiations cover depth-2 subgames of the game (max E*H, L*H, N over the shapes)

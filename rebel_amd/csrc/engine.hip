@@ -83,16 +83,25 @@ void Engine::construct() {
   emax_ = std::max(1, nmax_ - 1);
 
   d_shapes_.upload(tabs_.shapes, stream_);
-  d_parent_.upload(tabs_.parent, stream_);
-  d_act_.upload(tabs_.act, stream_);
-  d_cb_.upload(tabs_.cb, stream_);
-  d_ce_.upload(tabs_.ce, stream_);
-  d_depth_.upload(tabs_.depth, stream_);
-  d_leaves_.upload(tabs_.leaves, stream_);
-  d_terms_.upload(tabs_.terms, stream_);
-  d_irank_.upload(tabs_.irank, stream_);
-  d_leaf_row_.upload(tabs_.leaf_row, stream_);
-  std::vector<int8_t> m((size_t)g_.faces * g_.H);
+  // the one-wavefront CFR kernel reads these (and sigma / values below) with unconditional strided loads: kWavePad
+  // elements of slack behind each array keep its overruns inside the allocation
+  std::vector<std::vector<int>> keep;  // staging copies must outlive the asynchronous uploads (synchronised below)
+  keep.reserve(16);
+  auto padded = [&keep](std::vector<int> v) -> const std::vector<int>& {
+    v.resize(v.size() + kWavePad, 0);
+    keep.push_back(std::move(v));
+    return keep.back();
+  };
+  d_parent_.upload(padded(tabs_.parent), stream_);
+  d_act_.upload(padded(tabs_.act), stream_);
+  d_cb_.upload(padded(tabs_.cb), stream_);
+  d_ce_.upload(padded(tabs_.ce), stream_);
+  d_depth_.upload(padded(tabs_.depth), stream_);
+  d_leaves_.upload(padded(tabs_.leaves), stream_);
+  d_terms_.upload(padded(tabs_.terms), stream_);
+  d_irank_.upload(padded(tabs_.irank), stream_);
+  d_leaf_row_.upload(padded(tabs_.leaf_row), stream_);
+  std::vector<int8_t> m((size_t)g_.faces * g_.H + kWavePad);
   for (int f = 0; f < g_.faces; ++f)
     for (int h = 0; h < g_.H; ++h) m[(size_t)f * g_.H + h] = (int8_t)g_.matches(h, f);
   d_matches_.upload(m, stream_);
@@ -110,14 +119,14 @@ void Engine::construct() {
   d_lane_row_.alloc(L);
   d_lane_act_.alloc(L);
   d_beliefs_.alloc(L * 2 * g_.H);
-  d_sigma_.alloc(L * eh);
+  d_sigma_.alloc(L * eh + kWavePad);
   d_regrets_.alloc(L * eh);
   d_sums_.alloc(L * eh);
   d_snapshot_.alloc(L * eh);
   d_root_mean_.alloc(L * 2 * g_.H);
   const size_t max_rows = std::max<size_t>(1, L * tabs_.max_L);
   d_queries_.alloc(max_rows * g_.query_size());
-  d_values_.alloc(max_rows * g_.H);
+  d_values_.alloc(max_rows * g_.H + kWavePad);
   RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, max_rows * g_.H * sizeof(float), stream_));
   values_zeroed_ = true;
 
@@ -146,7 +155,7 @@ void Engine::construct() {
     for (const ShapeDev& s : tabs_.shapes) {
       max_eh = std::max(max_eh, (s.N - 1) * g_.H);
       max_lh = std::max(max_lh, s.L * g_.H);
-      wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, g_.faces));
+      wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces));
     }
     wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 &&
                cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
