@@ -155,11 +155,16 @@ def main():
         return net_t, cfr_t, net_tf, cfr_gb
 
     standalone = lanes4096 = None
-    if world == 1 and not a.no_extra_legs:
+    parts_env = os.environ.get("RBL_PARTS")
+    streams = int(parts_env) if parts_env else (1 if a.lanes >= 8192 else 2)  # the engine's default (engine.hip)
+    if world == 1 and not a.no_extra_legs and streams > 1:
         # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
         os.environ["RBL_PARTS"] = "1"
         sdt, sunits, _, _, sst, _ = run_leg(a.lanes, 1, 2, 4, False)
-        del os.environ["RBL_PARTS"]
+        if parts_env:
+            os.environ["RBL_PARTS"] = parts_env
+        else:
+            del os.environ["RBL_PARTS"]
         s_net_t, s_cfr_t, s_net_tf, s_cfr_gb = kernel_figures(sst)
         standalone = {"net": {"avg_launch_us": s_net_t * 1e6, "rows_per_launch": sst["net_rows"] / max(1, sst["net_launches"]),
                               "achieved": s_net_tf, "frac": s_net_tf / MFMA_F16_PEAK_TFLOPS,
@@ -168,6 +173,7 @@ def main():
                       "value_serial": sunits / sdt,
                       "note": "RBL_PARTS=1: one stream, net(all lanes) -> cfr(all lanes) per iteration; 1 warm-up + 2 timed "
                               "epochs from the root state (root-heavy mix: more rows per lane than the steady state)"}
+    if world == 1 and not a.no_extra_legs:
         if a.lanes != 4096:
             ldt, lunits, _, _, _, _ = run_leg(4096, 2, 3, 0, False)
             lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count), 2 warm-up + "
@@ -183,7 +189,8 @@ def main():
             except Exception:
                 continue
             for name, k in d.get("kernels", {}).items():
-                if kernel_key in name and "fetch_size_bytes_per_launch" in k and "write_size_bytes_per_launch" in k:
+                if any(key in name for key in kernel_key) and "fetch_size_bytes_per_launch" in k and \
+                        "write_size_bytes_per_launch" in k:
                     return {"bytes": k["fetch_size_bytes_per_launch"]["median"] + k["write_size_bytes_per_launch"]["median"],
                             "read": k["fetch_size_bytes_per_launch"]["median"],
                             "written": k["write_size_bytes_per_launch"]["median"],
@@ -226,17 +233,22 @@ def main():
                          "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),
                          "ns_per_row": net_t * 1e9 / max(1.0, st["net_rows"] / max(1, st["net_launches"])),
                          "algorithmic_flops_per_launch": st["net_flops"] / max(1, st["net_launches"]),
-                         "measured": "in-mix: HIP events on the launch's own stream, the other stream's CFR kernel active",
+                         "measured": ("HIP events on the engine stream; one stream, net(all lanes) -> cfr(all lanes) per iteration: "
+                                      "the kernel has the GPU to itself") if streams == 1 else
+                                     "in-mix: HIP events on the launch's own stream, the other stream's CFR kernel active",
                          "issued_mfma_tflops": net_tf * issued_ratio,
                          "vs_f32_mfma_peak": net_tf / MFMA_F32_PEAK_TFLOPS},
-            "roofline_cfr": {"kernel": "cfr_rows_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
+            "roofline_cfr": {"kernel": "cfr_wave_kernel (one wavefront per lane)" if os.environ.get("RBL_CFR_WAVE", "1") != "0" and
+                             (a.dice, a.faces) in ((1, 6), (1, 4), (1, 5), (2, 3)) else "cfr_rows_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
                              "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"],
                              "algorithmic_bytes_per_launch": st["cfr_bytes"] / max(1, st["cfr_launches"]),
-                             "measured": "in-mix: HIP events on the launch's own stream, the other stream's net kernel active"},
+                             "measured": "HIP events on the engine stream; the kernel has the GPU to itself" if streams == 1 else
+                                         "in-mix: HIP events on the launch's own stream, the other stream's net kernel active"},
+            "streams": streams,
             "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
         }
-        for key, kern in (("roofline", "mlp_resident_kernel"), ("roofline_cfr", "cfr_")):
+        for key, kern in (("roofline", ("mlp_resident_kernel",)), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
             tr = pmc_traffic(kern)
             if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
                 scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0

@@ -59,7 +59,11 @@ void Engine::construct() {
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_x_[i], hipStreamNonBlocking));
-  max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", 2)));
+  // Lane parts on separate streams: with >= 8192 lanes the launches are long enough that one stream (net forward over all
+  // lanes, then the CFR step over all lanes) loses only ~3 % to kernel tails and launch gaps, and every kernel then runs
+  // with the GPU to itself (measured durations are the kernels' own); smaller batches gain 5-8 % from two interleaved
+  // half-batches whose tails overlap (bench numbers in DESIGN.md).
+  max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", max_lanes_ >= 8192 ? 1 : 2)));
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
   split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
