@@ -122,6 +122,11 @@ int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out);
  * the reference's solver-construction order) and contributes its sampling strategy.  root_only != 0: subgames below the
  * root are solved to the end of the game without the net (max_depth = 100000), on a helper engine of the same device. */
 int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, double* out);
+/* compute_immediate_regrets (subgame_solving.cc:984-1050; printed by recursive_eval --print_regret[_summary],
+ * recursive_eval.cc:28-53): strategies = n_strategies dense full-tree strategies [N_full][H][A] back to back; out[N_full][H] =
+ * max over the actions of the regret accumulated over all strategies and both traversers, divided by n_strategies (0 on
+ * nodes without children).  Runs as plain CFR regret updates of a full-tree solver on the device. */
+int rbl_immediate_regrets(int device, int dice, int faces, const double* strategies, int n_strategies, double* out);
 int rbl_solver_hand_values(rbl_engine* e, int lane, int player, double* out); /* get_hand_values :694-696 */
 /* update_value_network (:672-676): writes the lane's two training examples, queries[2][Q], values[2][H] */
 int rbl_solver_examples(rbl_engine* e, int lane, float* queries, float* values);

@@ -900,6 +900,57 @@ void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float*
                        int num_actions) {
   synthetic_net(queries, rows, qsize, out, osize, num_actions);
 }
+// compute_immediate_regrets (subgame_solving.cc:984-1050) restated: strategies [K][N][H][A] back to back -> out [N][H]
+void orc_immediate_regrets(int dice, int faces, const double* strategies, int n_strategies, double* out) {
+  Rules g(dice, faces);
+  Net none;
+  Traverser t(g, unroll(g, -1, 0, 1000000), none, false);
+  const int H = g.H, A = g.A, N = t.N;
+  const size_t stride = (size_t)N * H * A;
+  std::vector<double> regrets(stride, 0.0), uniform(H, 1. / H);
+  for (int k = 0; k < n_strategies; ++k) {
+    const std::vector<double> sg(strategies + (size_t)k * stride, strategies + (size_t)(k + 1) * stride);
+    t.sweep_reach(sg, uniform.data(), 0, t.reach[0]);  // precompute_reaches(last_strategies, initial_beliefs, 0 / 1)
+    t.sweep_reach(sg, uniform.data(), 1, t.reach[1]);
+    for (int trav = 0; trav < 2; ++trav) {
+      t.leaf_values(trav);
+      for (int n = N; n-- > 0;) {
+        const Node& nd = t.tree[n];
+        if (nd.cb == nd.ce) continue;
+        double* v = &t.value[(size_t)n * H];
+        for (int h = 0; h < H; ++h) v[h] = 0.0;
+        int lo, hi;
+        g.bid_range(nd.last_bid, &lo, &hi);
+        if (nd.player == trav) {
+          for (int c = nd.cb, a = lo; c < nd.ce; ++c, ++a) {
+            const double* cv = &t.value[(size_t)c * H];
+            for (int h = 0; h < H; ++h) {
+              regrets[((size_t)n * H + h) * A + a] += cv[h];
+              v[h] += cv[h] * sg[((size_t)n * H + h) * A + a];
+            }
+          }
+          for (int h = 0; h < H; ++h)
+            for (int c = nd.cb, a = lo; c < nd.ce; ++c, ++a) regrets[((size_t)n * H + h) * A + a] -= v[h];
+        } else {
+          for (int c = nd.cb; c < nd.ce; ++c) {
+            const double* cv = &t.value[(size_t)c * H];
+            for (int h = 0; h < H; ++h) v[h] += cv[h];
+          }
+        }
+      }
+    }
+  }
+  for (int n = 0; n < N; ++n)
+    for (int h = 0; h < H; ++h) {
+      double best = 0.0;
+      if (t.tree[n].cb != t.tree[n].ce) {
+        const double* r = &regrets[((size_t)n * H + h) * A];
+        best = *std::max_element(r, r + A) / n_strategies;
+      }
+      out[(size_t)n * H + h] = best;
+    }
+}
+
 // The reference's random draws come from libstdc++ <random> driven by std::mt19937 (recursive_solving.cc:168-169, 198-215):
 // per round uniform_int_distribution<int>(0, hi), uniform_real_distribution<float>(0, 1), discrete_distribution<int>(w).
 // The device restatement (rebel_amd/csrc/selfplay_kernels.hip) is checked against this draw for draw.

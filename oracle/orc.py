@@ -105,8 +105,18 @@ class Oracle:
         L.orc_synthetic_net.argtypes = [C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                                         C.c_int]
         L.orc_synthetic_net.restype = None
+        L.orc_immediate_regrets.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        L.orc_immediate_regrets.restype = None
         L.orc_rng_probe.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
         L.orc_rng_probe.restype = None
+
+    def immediate_regrets(self, d, f, strategies):
+        """compute_immediate_regrets (subgame_solving.cc:984-1050): float64[K, N_full, H, A] -> float64[N_full, H]."""
+        s = np.ascontiguousarray(strategies, np.float64)
+        out = np.zeros((s.shape[1], s.shape[2]))
+        self.lib.orc_immediate_regrets(d, f, s.ctypes.data_as(C.POINTER(C.c_double)), s.shape[0],
+                                       out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def rng_probe(self, seed, rounds, hi, weights):
         """libstdc++ draws from std::mt19937(seed): float64[rounds, 3] = uniform_int(0, hi), uniform_real<float>, discrete."""

@@ -87,6 +87,10 @@ void orc_compute_ev2(int dice, int faces, const double* strategy1, const double*
  *   v[h] = ((0.5f*q[2+A+h] - 0.25f*q[2+A+H+h]) + 0.125f*(q[1]-q[0])) + 0.0625f*q[2 + h % A]                      */
 void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float* out, int64_t osize, int num_actions);
 
+/* ---- compute_immediate_regrets (subgame_solving.cc:984-1050): strategies = n_strategies dense [N_full][H][A] arrays back
+ *      to back; out [N_full][H] ---- */
+void orc_immediate_regrets(int dice, int faces, const double* strategies, int n_strategies, double* out);
+
 /* libstdc++ <random> as the reference uses it: out[3*rounds] = per round uniform_int(0, hi), uniform_real<float>(0,1),
  * discrete(w[0..nw)) from std::mt19937(seed) -- the yardstick for the device-side restatement of those algorithms */
 void orc_rng_probe(int seed, int rounds, int hi, const double* w, int nw, double* out);

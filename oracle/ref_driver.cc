@@ -317,6 +317,23 @@ void orc_synthetic_net(const float* queries, int64_t rows, int64_t qsize, float*
     }
   }
 }
+void orc_immediate_regrets(int dice, int faces, const double* strategies, int n_strategies, double* out) {
+  Game game(dice, faces);
+  const auto tree = unroll_tree(game);
+  const int H = game.num_hands(), A = game.num_actions();
+  const size_t stride = tree.size() * (size_t)H * A;
+  std::vector<TreeStrategy> list(n_strategies);
+  for (int k = 0; k < n_strategies; ++k) {
+    init_nd((int)tree.size(), H, A, 0.0, &list[k]);
+    for (size_t n = 0; n < tree.size(); ++n)
+      for (int h = 0; h < H; ++h)
+        for (int a = 0; a < A; ++a) list[k][n][h][a] = strategies[(size_t)k * stride + (n * H + h) * A + a];
+  }
+  const auto r = compute_immediate_regrets(game, list);  // subgame_solving.cc:984-1050, unmodified
+  for (size_t n = 0; n < tree.size(); ++n)
+    for (int h = 0; h < H; ++h) out[n * H + h] = r[n][h];
+}
+
 // The reference's random draws come from libstdc++ <random> driven by std::mt19937 (recursive_solving.cc:168-169, 198-215):
 // per round uniform_int_distribution<int>(0, hi), uniform_real_distribution<float>(0, 1), discrete_distribution<int>(w).
 // The device restatement (rebel_amd/csrc/selfplay_kernels.hip) is checked against this draw for draw.

@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -114,6 +114,7 @@ def lib():
         "rbl_strategy_recursive": (C.c_int, [vp, C.c_int, dp]),
         "rbl_solver_evaluate": (C.c_int, [vp, C.c_int, dp]),
         "rbl_ev2": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, dp]),
+        "rbl_immediate_regrets": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
         "rbl_strategy_recursive_sampled": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_hand_values": (C.c_int, [vp, C.c_int, C.c_int, dp]),
         "rbl_solver_examples": (C.c_int, [vp, C.c_int, fp, fp]),
@@ -183,6 +184,15 @@ def ev2(dice, faces, strategy1, strategy2, device=0):
     b = np.ascontiguousarray(strategy2, np.float64)
     out = np.zeros(2)
     _check(lib().rbl_ev2(device, dice, faces, _p(a, C.c_double), _p(b, C.c_double), _p(out, C.c_double)))
+    return out
+
+
+def immediate_regrets(dice, faces, strategies, device=0):
+    """compute_immediate_regrets (subgame_solving.cc:984-1050): strategies float64[K, N_full, H, A] -> float64[N_full, H]."""
+    s = np.ascontiguousarray(strategies, np.float64)
+    K, N, H = s.shape[0], s.shape[1], s.shape[2]
+    out = np.zeros((N, H))
+    _check(lib().rbl_immediate_regrets(device, dice, faces, _p(s, C.c_double), K, _p(out, C.c_double)))
     return out
 
 

@@ -1616,6 +1616,47 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
 int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out) {
   return guard([&] { need(e).evaluate(traverser, out); });
 }
+int rbl_immediate_regrets(int device, int dice, int faces, const double* strategies, int n_strategies, double* out) {
+  return guard([&] {  // compute_immediate_regrets (subgame_solving.cc:984-1050) on the full tree
+    // For every strategy and traverser the reference sweeps the tree bottom-up under that strategy and accumulates
+    // regrets[node][hand][action] += value(child) - value(node): exactly the regret update of one plain CFR step (no
+    // discount) with sigma = the strategy.  So: a full-tree solver with use_cfr and no linear / DCFR weighting, sigma reset
+    // to the strategy before each traverser's step (the step's regret matching overwrites the traverser's rows), regrets
+    // left to accumulate on the device across all strategies; the maximum over the actions is taken at the end.
+    if (!strategies || !out || n_strategies < 1) throw std::runtime_error("rbl_immediate_regrets: bad arguments");
+    rbl_params p{};
+    p.num_iters = 2 * n_strategies;
+    p.max_depth = 1000000;
+    p.use_cfr = 1;
+    rbl::Engine e(device, dice, faces, p, 1);
+    e.set_net_zero();
+    const rbl::Rules& g = e.rules();
+    const int H = g.H, A = g.A;
+    const std::vector<rbl::Node> full = rbl::unroll_tree(g, -1, 0, 1000000);
+    const size_t stride = full.size() * (size_t)H * A;
+    std::vector<double> b(2 * H, 1. / H), reg(stride);
+    const int32_t rb = -1, rp = 0;
+    e.reset(1, &rb, &rp, b.data(), nullptr);
+    for (int k = 0; k < n_strategies; ++k)
+      for (int t = 0; t < 2; ++t) {
+        e.set_strategy(0, strategies + (size_t)k * stride);
+        e.step(t);
+      }
+    e.get(0, RBL_GET_REGRETS, reg.data());
+    for (size_t n = 0; n < full.size(); ++n)
+      for (int h = 0; h < H; ++h) {
+        double best = 0.0;
+        if (full[n].cb != full[n].ce) {
+          // std::max_element over ALL actions of the dense row: illegal actions hold 0 (subgame_solving.cc:1041-1044)
+          const double* r = reg.data() + (n * H + h) * A;
+          best = r[0];
+          for (int a = 1; a < A; ++a) best = r[a] > best ? r[a] : best;
+          best /= n_strategies;
+        }
+        out[n * H + h] = best;
+      }
+  });
+}
 int rbl_ev2(int device, int dice, int faces, const double* strategy1, const double* strategy2, double out[2]) {
   return guard([&] {  // compute_ev2 (subgame_solving.cc:975-982): player 0 follows one strategy, player 1 the other
     rbl_params p{};

@@ -997,16 +997,21 @@ float compute_exploitability_no_net(RecursiveSolvingParams params) {
   std::vector<double> b(2 * (size_t)H, 1. / H), strategy((size_t)n * H * A);
   const int32_t rb = -1, rp = 0;
   check(rbl_solver_reset(ev.e, 1, &rb, &rp, b.data(), nullptr), "reset");
+  // REBEL_AMD_REFERENCE_QUIRKS=1 reproduces the reference to the letter (pybind.cc:86-105): the solver is never stepped,
+  // the printed numbers are those of the initial uniform strategy every time, and the function returns 0 (its outer
+  // `values` is shadowed by the loop-local one).
+  const char* quirks_env = std::getenv("REBEL_AMD_REFERENCE_QUIRKS");
+  const bool quirks = quirks_env && *quirks_env && *quirks_env != '0';
   double ex[2] = {0, 0};
   for (int iter = 0; iter < sp.num_iters; ++iter) {
-    check(rbl_solver_step(ev.e, iter % 2), "step");
+    if (!quirks) check(rbl_solver_step(ev.e, iter % 2), "step");
     if (((iter + 1) & iter) == 0 || iter + 1 == sp.num_iters) {
       check(rbl_solver_get(ev.e, 0, RBL_GET_AVERAGE, strategy.data()), "get");
       check(rbl_exploitability2(eval_device(), params.num_dice, params.num_faces, strategy.data(), ex), "exploitability2");
       std::printf("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e\n", iter + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2.);
     }
   }
-  return (float)((ex[0] + ex[1]) / 2.);
+  return quirks ? 0.0f : (float)((ex[0] + ex[1]) / 2.);
 }
 
 }  // namespace

@@ -14,7 +14,10 @@ What it reproduces:
   * the machine-readable line `XXX {"net":..., "full_tree":..., "repeated toleaf N":...}` that scripts/eval_all.py:100-104
     greps for.
   * the `YYY {...}` line: EV of the full-tree strategy against each evaluated strategy (compute_ev2, rbl_ev2).
-Not reproduced: regret reports, strategy dumps, oracle-net mode.
+  * `--print_regret` / `--print_regret_summary` (recursive_eval.cc:28-53): immediate regrets of the list of sampled
+    strategies (compute_immediate_regrets, subgame_solving.cc:984-1050 -> rbl_immediate_regrets), CFR runs only, as in
+    the reference (:354-357).
+Not reproduced: strategy dumps, oracle-net mode.
 """
 import argparse
 import json
@@ -58,6 +61,8 @@ def main():
     ap.add_argument("--no_linear", action="store_true")
     ap.add_argument("--optimistic", action="store_true")
     ap.add_argument("--cfr", action="store_true")
+    ap.add_argument("--print_regret", action="store_true")
+    ap.add_argument("--print_regret_summary", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max_lanes", type=int, default=4096)
     a = ap.parse_args()
@@ -103,8 +108,25 @@ def main():
                 sd = torch.load(a.net, map_location="cpu")
             eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
         summed = reach_sum = None
+        strategy_list = []
+
+        def regret_report():  # report_regrets, recursive_eval.cc:28-53
+            if not strategy_list or not (a.print_regret or a.print_regret_summary):
+                return ""
+            reg = capi.immediate_regrets(d, f, np.stack(strategy_list), a.device)
+            out = ""
+            if a.print_regret:
+                out += "\tRegrets: " + "".join(" ".join("%g" % x for x in reg[n]) + " | " for n in range(min(20, len(reg)))) + "\n"
+            if a.print_regret_summary:
+                top = sum(reg[n].sum() for n in range(len(tree)) if tree[n][5] < a.mdp_depth)
+                out += "\tRegrets (depth<=%d)/rest: %g/%g" % (a.mdp_depth, top, reg.sum() - top)
+            return out
+
         for sid in range(max(a.num_repeats, 0)):
-            s = eng.strategy_recursive_sampled(sid, a.root_only).astype(np.float32)
+            s64 = eng.strategy_recursive_sampled(sid, a.root_only)
+            if a.cfr:
+                strategy_list.append(s64.astype(np.float32).astype(np.float64))  # tensor_to_tree_strategy of a float tensor
+            s = s64.astype(np.float32)
             w = reach_of_actor(tree, s.astype(np.float64), H).astype(np.float32)[:, :, None]
             summed = s * w if summed is None else summed + s * w
             reach_sum = w if reach_sum is None else reach_sum + w
@@ -113,7 +135,7 @@ def main():
                 ex = capi.exploitability2(d, f, final, a.device)
                 ev = capi.ev2(d, f, full_strategy, final, a.device)  # compute_ev2(game, full_strategy, final_strategy), :370
                 print("%5d: %.6f (%.6f,%.6f)\tEV of full: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1],
-                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1]))
+                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1]) + regret_report())
                 results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
                 results_ev.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
     for name, val in results[1:]:

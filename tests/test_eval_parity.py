@@ -120,7 +120,8 @@ def test_recursive_eval_tool(tmp_path):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py"), "--num_dice", "1", "--num_faces",
-                        "4", "--subgame_iters", "64", "--mdp_depth", "100", "--num_repeats", "8", "--net", "zero", "--cfr"],
+                        "4", "--subgame_iters", "64", "--mdp_depth", "100", "--num_repeats", "8", "--net", "zero", "--cfr",
+                        "--print_regret_summary"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("XXX ")][-1]
@@ -128,5 +129,21 @@ def test_recursive_eval_tool(tmp_path):
     assert d["net"] == "zero" and float(d["full_tree"]) < 0.05
     assert float(d["repeated toleaf 8"]) < float(d["repeated toleaf 1"])
     assert "Iter=      64" in r.stdout
+    assert r.stdout.count("Regrets (depth<=100)/rest: ") == 4  # report_regrets at 1, 2, 4, 8 repeats (recursive_eval.cc:41-52)
     ev = json.loads([l for l in r.stdout.splitlines() if l.startswith("YYY ")][-1][4:])
     assert set(ev) == set(d) and abs(float(ev["full_tree"])) < 1e-6  # EV of the full-tree strategy against itself
+
+
+def test_immediate_regrets_bit_exact(port):
+    """rbl_immediate_regrets (compute_immediate_regrets, subgame_solving.cc:984-1050; recursive_eval's --print_regret
+    reports): plain-CFR regret updates of a full-tree solver on the device, against the oracle (pinned to the compiled
+    reference in tests/test_oracle_pin.py)."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    for d, f, k in ((1, 3, 3), (1, 4, 4), (2, 2, 2)):
+        S = np.stack([port.strategy_recursive(d, f, orc.make_params(num_iters=12 + 9 * i, max_depth=2, linear_update=True,
+                                                                       use_cfr=True), to_leaf=True) for i in range(k)])
+        got, want = capi.immediate_regrets(d, f, S), port.immediate_regrets(d, f, S)
+        assert np.array_equal(got, want), (d, f, np.abs(got - want).max())
+        assert np.abs(want).max() > 0.01

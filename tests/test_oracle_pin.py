@@ -122,3 +122,13 @@ def test_ev2_port_vs_reference(d, f, ref, port):
     a, b = s1.get(orc.GET_AVERAGE), s2.get(orc.GET_LAST)
     assert np.array_equal(ref.ev2(d, f, a, b), port.ev2(d, f, a, b))
     assert np.array_equal(ref.ev2(d, f, b, a), port.ev2(d, f, b, a))
+
+
+def test_immediate_regrets_port_equals_reference(port, ref):
+    """compute_immediate_regrets (subgame_solving.cc:984-1050): the restatement against the compiled reference on strategy
+    lists produced by recursive solving (1dx3f and 1dx4f full trees)."""
+    for d, f, k in ((1, 3, 3), (1, 4, 2)):
+        S = np.stack([ref.strategy_recursive(d, f, orc.make_params(num_iters=16 + 8 * i, max_depth=2, linear_update=True,
+                                                                      use_cfr=True), to_leaf=True) for i in range(k)])
+        a, b = ref.immediate_regrets(d, f, S), port.immediate_regrets(d, f, S)
+        assert np.array_equal(a, b) and np.abs(a).max() > 0.01

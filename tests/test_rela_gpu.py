@@ -198,6 +198,12 @@ def test_eval_helpers_against_oracle(tmp_path, port):
     cfg2 = _cfg(rela, 1, 2, 180)
     total = rela.compute_exploitability_fp(cfg2)
     assert 0 <= total < 1e-3  # subgame_solving_test.cc:162-179
+    import os
+    os.environ["REBEL_AMD_REFERENCE_QUIRKS"] = "1"  # the reference to the letter: never steps, returns 0 (pybind.cc:86-105)
+    try:
+        assert rela.compute_exploitability_fp(cfg2) == 0.0
+    finally:
+        del os.environ["REBEL_AMD_REFERENCE_QUIRKS"]
 
 
 def test_device_replay_ring_equals_host_ring(tmp_path):
