@@ -28,8 +28,9 @@ while True:
     n = replay.num_add()
     if t0 is None and n >= 2 * lanes:  # first epoch done: start the clock
         t0, n0 = time.time(), n
-    if t0 is not None and time.time() - t0 > 6:
+    if t0 is not None and time.time() - t0 > (float(sys.argv[2]) if len(sys.argv) > 2 else 8):
         dt = time.time() - t0
-        print(f"lanes {lanes}: {(n - n0) / 2 * iters / dt / 1e6:.2f} M subgame-CFR-iterations/s through rela ({(n - n0) / dt:.0f} examples/s)")
+        print(f"lanes {lanes}: {(n - n0) / 2 * iters / dt / 1e6:.2f} M subgame-CFR-iterations/s through rela ({(n - n0) / dt:.0f} examples/s); "
+              f"replay ring on {replay._storage_device()}")
         break
 ctx.terminate()
