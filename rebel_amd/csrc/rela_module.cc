@@ -795,6 +795,12 @@ class Context {  // rela/context.h:26-85
     started_ = true;
     workers_.clear();
     plan();
+    for (auto& w : workers_)
+      if (w->n_loops > 1000)  // selfplay.py:250 seeds lanes rank*1000 + i: beyond 1000 per rank they repeat the next rank's
+        std::fprintf(stderr,
+                     "rebel_amd.rela: warning: %d create_cfr_thread calls share one ModelLocker; with the reference's seed "
+                     "convention (rank*1000+i) lanes beyond 1000 duplicate another rank's games -- keep threads_per_gpu <= "
+                     "1000 and scale with REBEL_AMD_LANES_PER_THREAD\n", w->n_loops);
     for (auto& w : workers_) {  // engines are created here so that configuration errors surface as Python exceptions
       const rbl_params p = to_c(w->cfg.subgame_params);
       w->engine = rbl_engine_create(w->locker->device_index, w->cfg.num_dice, w->cfg.num_faces, &p, (int)w->seeds.size());
