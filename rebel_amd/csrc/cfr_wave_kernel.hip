@@ -20,6 +20,8 @@
 // -ffp-contract=off, explicit fmas only where those kernels have them), so the bit-exactness contract with the reference
 // (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py and tests/test_selfplay_parity.py run against it.
 // Only kModeStep of LDS-resident lanes runs here (RBL_CFR_WAVE=0 switches back to the row kernel).
+#include <type_traits>
+
 #include "cfr_kernels.h"
 
 namespace rbl {
@@ -126,16 +128,36 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   float lv_[KL][H];
   {
     const float* gv = a.values + ((size_t)row_off + tid) * H;
+    // one wave-uniform choice of how many 64-row strides the lane's L rows need (a test per stride would serialise the
+    // loads; always loading the maximum made small trees read their neighbours' rows: 1.9x fabric traffic)
+    auto load_lv = [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
 #pragma unroll
-    for (int u = 0; u < KL; ++u)
+      for (int u = 0; u < K; ++u)
 #pragma unroll
-      for (int h = 0; h < H; ++h) lv_[u][h] = gv[(size_t)u * W * H + h];
+        for (int h = 0; h < H; ++h) lv_[u][h] = gv[(size_t)u * W * H + h];
+    };
+    if (KL >= 2 && L > W)
+      load_lv(std::integral_constant<int, KL>{});
+    else if (L > 0)
+      load_lv(std::integral_constant<int, 1>{});
   }
   {
     double s_[KS];
     const double* gs0 = g_sig + tid;
+    constexpr int KS3 = (KS + 2) / 3, KS23 = (2 * KS + 2) / 3;  // thirds of the stride count, same wave-uniform choice
+    auto load_sig = [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) s_[u] = gs0[u * W];
+      for (int u = 0; u < K; ++u) s_[u] = gs0[u * W];
+    };
+    const int sig_strides = EH <= KS3 * W ? KS3 : (EH <= KS23 * W ? KS23 : KS);
+    if (sig_strides == KS3)
+      load_sig(std::integral_constant<int, KS3>{});
+    else if (sig_strides == KS23)
+      load_sig(std::integral_constant<int, KS23>{});
+    else
+      load_sig(std::integral_constant<int, KS>{});
     // (the net's output rows go straight into the registers of the thread that will consume them: lv_ below)
     const int* gp = a.parent + node_off + tid;
     const int* ga = a.act + node_off + tid;
@@ -163,8 +185,17 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       rmean_t = rmean[t * H + tid];
     }
     const double b0 = tid < H ? (t == 0 ? bel_t : bel[tid]) : 0.0, b1 = tid < H ? (t == 1 ? bel_t : bel[H + tid]) : 0.0;
+    auto store_sig = [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) sig[tid + u * W] = s_[u];
+      for (int u = 0; u < K; ++u) sig[tid + u * W] = s_[u];
+    };
+    if (sig_strides == KS3)
+      store_sig(std::integral_constant<int, KS3>{});
+    else if (sig_strides == KS23)
+      store_sig(std::integral_constant<int, KS23>{});
+    else
+      store_sig(std::integral_constant<int, KS>{});
     if (tid < H) {
       rho0[tid] = b0;
       rho1[tid] = b1;

@@ -314,3 +314,20 @@ def test_2d6f_root_2048_iterations_bit_exact(port):
             assert np.array_equal(e.get(b, w), o.get(ow)), (b, w)
         for pl in (0, 1):
             assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
+
+
+@pytest.mark.parametrize("name", ["1d6f_root_syn_1024", "2d3f_bid2_p1_syn_256", "1d4f_dcfr_syn_64"])
+def test_row_kernel_fallback_bit_exact(name, port, monkeypatch):
+    """RBL_CFR_WAVE=0: the row-per-thread kernel (the fallback of the one-wavefront kernel, and the kernel deeper subgames
+    run on) reaches the same golden end state."""
+    from rebel_amd import capi
+
+    monkeypatch.setenv("RBL_CFR_WAVE", "0")
+    c = SOLVER_CASES[name]
+    e = _engine(c)
+    b = case_beliefs(c, e.H)
+    e.reset([c.get("lb", -1)], [c.get("pl", 0)], b[None])
+    e.multistep()
+    arrays = {"average": e.get(0, capi.GET_AVERAGE), "last": e.get(0, capi.GET_LAST), "sum": e.get(0, capi.GET_SUM),
+              "regrets": e.get(0, capi.GET_REGRETS)}
+    G.check_solver_arrays(name, arrays, np.stack([e.hand_values(0, 0), e.hand_values(0, 1)]), exact=True)
