@@ -176,3 +176,38 @@ def test_selfplay_games_counter_and_callback_net_falls_back_to_host(port):
                           net=orc.NET_SYNTHETIC)
         for (q, v), (rq, rv) in zip(got[i], ref):
             assert np.array_equal(q, rq) and np.array_equal(v, rv)
+
+
+def test_selfplay_at_bench_size_vs_oracle(port):
+    """The bench's own configuration -- 1dx6f, 1024 iterations per subgame, 16 384 lanes on one stream, device walk -- with
+    the synthetic net in place of Net2 so that parity is exact: after two epochs a sample of lanes equals the oracle's
+    example stream for its seed bit for bit, every emitted belief vector is a probability vector, and the games counter
+    equals the number of lanes that reached a terminal state."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    d, f, iters, B = 1, 6, 1024, 16384
+    p = dict(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+    e = capi.Engine(d, f, capi.make_params(**p), max_lanes=B)
+    e.set_net_synthetic()
+    seeds = list(range(B))
+    sp = capi.SelfPlay(e, seeds, random_action_prob=0.25, sample_leaf=True)
+    got, finished = [[] for _ in range(B)], 0
+    sample = list(range(0, B, 1371)) + [B - 1]
+    for _ in range(2):
+        n, lanes, q, v = sp.advance()
+        assert n == B * iters and sp.on_device() == 1
+        assert np.isfinite(q).all() and np.isfinite(v).all()
+        A, H = e.A, e.H
+        assert np.allclose(q[:, 2 + A:2 + A + H].sum(1), 1, atol=1e-5) and np.allclose(q[:, 2 + A + H:].sum(1), 1, atol=1e-5)
+        assert set(np.unique(q[:, :2 + A])) <= {0.0, 1.0} and (q[:, 2:2 + A].sum(1) <= 1).all()
+        for i in sample:
+            got[i] += [(q[2 * i], v[2 * i]), (q[2 * i + 1], v[2 * i + 1])]
+        finished += sum(1 for i in range(0, B, 97) if sp.state(i)[0] == e.A - 1)
+    assert sp.games_finished() >= finished > 0
+    for i in sample:
+        ref = port.rl_run(d, f, orc.make_params(**p), seeds[i], 2, random_action_prob=0.25, sample_leaf=True,
+                          net=orc.NET_SYNTHETIC)
+        assert len(ref) >= 4
+        for (q, v), (rq, rv) in zip(got[i], ref[:4]):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), i
