@@ -276,3 +276,46 @@ def test_datagen_appends_to_the_device_ring_and_tiny_buffers_do_not_stall():
         assert time.time() - t0 < 120, "producer stalled on a full buffer"
     ctx.terminate()
     _wait(ctx.terminated, 60)
+
+
+def test_two_workers_share_one_replay():
+    """The in-process multi-GPU topology on one device: two ModelLockers (= two generating GPUs in selfplay.py:187-252) give
+    two engines with their own driver threads, both block-appending into the same device-resident replay; update_model on
+    each locker reaches its own engine; terminate() stops both."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    torch.manual_seed(0)
+    net = Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2)
+    models = [torch.jit.script(Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2).to("cuda:0")).eval()
+              for _ in range(2)]
+    for m in models:
+        m.load_state_dict(net.state_dict())
+    lockers = [rela.ModelLocker([m], "cuda:0") for m in models]
+    replay = rela.ValuePrioritizedReplay(capacity=1 << 15, seed=5, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    ctx = rela.Context()
+    cfg = _cfg(rela, 1, 4, 32)
+    lanes = (48, 80)  # different lane counts: the workers' epochs are told apart by their example counts
+    seed = 0
+    for k, locker in enumerate(lockers):
+        for _ in range(lanes[k]):
+            ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, seed))
+            seed += 1
+    assert [(dev, n) for dev, _, n, _ in ctx._plan()] == [("cuda:0", 48), ("cuda:0", 80)]
+    ctx.start()
+    _wait(lambda: replay.num_add() >= 8 * sum(lanes))
+    for locker in lockers:
+        locker.update_model(net)
+    n0 = replay.num_add()
+    _wait(lambda: replay.num_add() >= n0 + 4 * sum(lanes))
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    n = replay.num_add()
+    # whole epochs of either worker: n = 96 a + 160 b with both a, b > 0
+    assert any((n - 96 * a) % 160 == 0 and (n - 96 * a) > 0 for a in range(1, n // 96 + 1))
+    assert replay._storage_device() == "cuda:0"
+    b, _ = replay.sample(256, "cuda:0")
+    assert torch.isfinite(b.values).all() and b.query.shape == (256, 19)
