@@ -211,3 +211,20 @@ def test_selfplay_at_bench_size_vs_oracle(port):
         assert len(ref) >= 4
         for (q, v), (rq, rv) in zip(got[i], ref[:4]):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), i
+
+
+def test_selfplay_full_depth_subgames_need_no_net(port):
+    """max_depth beyond the game's length: every subgame is the whole remaining game, there are no pseudo-leaves and no
+    net rows at all (the device epoch then runs CFR launches only); trajectories still equal the oracle's."""
+    from oracle import orc
+
+    c = dict(d=1, f=4, p=dict(num_iters=40, max_depth=100, linear_update=True, use_cfr=True), rap=0.25, leaf=True,
+             net="zero")
+    seeds = [61, 62, 63, 64, 65]
+    lanes = _run_lanes(c, seeds, 3)
+    for seed, ex in zip(seeds, lanes):
+        ref = port.rl_run(c["d"], c["f"], orc.make_params(**c["p"]), seed, 3, random_action_prob=c["rap"],
+                          sample_leaf=c["leaf"], net=orc.NET_ZERO)
+        assert len(ex) == len(ref), seed
+        for (q, v), (rq, rv) in zip(ex, ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
