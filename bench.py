@@ -14,10 +14,11 @@ lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
-                measured live with HIP events on the engine streams over the timed region (every 8th iteration; the two
-                half-batches run on two streams, so a launch covers half the lanes and is time-sliced against the other
-                half's CFR kernel: "in-mix"), plus `standalone`: the same kernel timed in a short extra leg where the
-                launches of an iteration run back to back on ONE stream (what the kernel does when it owns the GPU)
+                measured live with HIP events on the engine stream over the timed region (every 8th iteration).  At the
+                default 16 384 lanes the engine runs ONE stream -- net(all lanes) -> cfr(all lanes) per iteration -- so a
+                kernel has the GPU to itself and the durations are its own; below 8 192 lanes it interleaves two half-
+                batches on two streams ("in-mix" durations) and `standalone` then carries the one-stream figures of a
+                short extra leg
   roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration, in-mix + standalone
   traffic       HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, separate
                 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH x2 per the gfx950 note of the guide)

@@ -421,8 +421,8 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_lane_row_.upload(h_row_, stream_);
   d_lane_act_.upload(h_act_, stream_);
   d_beliefs_.upload(h_beliefs_, stream_);
-  // two half-batches on two streams: one half's CFR step overlaps the other half's value-net forward (the two
-  // kernels stress different units); halves are independent lane sets, rows of a half are contiguous
+  // lane parts (parts_for: one below 8192-lane engines' threshold, see the constructor): independent lane sets on their
+  // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
   part_lanes(B, part_lane_);
   for (int pt = 0; pt <= n_parts_; ++pt) part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
