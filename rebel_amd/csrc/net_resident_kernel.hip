@@ -423,9 +423,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       float* og = out + row0 * n_out;
       const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
       if (r_in < rows_here) {
+        if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
+          f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
+          if (col + 1 < n_out) p2[0] = f32x2{r4[0], r4[1]};
+          if (col + 3 < n_out) p2[1] = f32x2{r4[2], r4[3]};
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+          for (int r = 0; r < 4; ++r)
+            if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+        }
       }
     }
     // -------------------------------------------------------------- further output tiles (n_out > 16): from the X image
