@@ -16,7 +16,7 @@ The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
                 measured live with HIP events on the engine stream over the timed region (every 8th iteration).  At the
                 default 16 384 lanes the engine runs ONE stream -- net(all lanes) -> cfr(all lanes) per iteration -- so a
-                kernel has the GPU to itself and the durations are its own; below 8 192 lanes it interleaves two half-
+                kernel has the GPU to itself and the durations are its own; below 16 384 lanes it interleaves two half-
                 batches on two streams ("in-mix" durations) and `standalone` then carries the one-stream figures of a
                 short extra leg
   roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration, in-mix + standalone
@@ -157,7 +157,7 @@ def main():
 
     standalone = lanes4096 = None
     parts_env = os.environ.get("RBL_PARTS")
-    streams = int(parts_env) if parts_env else (1 if a.lanes >= 8192 else 2)  # the engine's default (engine.hip)
+    streams = int(parts_env) if parts_env else (1 if a.lanes >= 16384 else 2)  # the engine's default (engine.hip)
     if world == 1 and not a.no_extra_legs and streams > 1:
         # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
         os.environ["RBL_PARTS"] = "1"
@@ -174,6 +174,14 @@ def main():
                       "value_serial": sunits / sdt,
                       "note": "RBL_PARTS=1: one stream, net(all lanes) -> cfr(all lanes) per iteration; 1 warm-up + 2 timed "
                               "epochs from the root state (root-heavy mix: more rows per lane than the steady state)"}
+    two_streams = None
+    if world == 1 and not a.no_extra_legs and streams == 1 and not parts_env:
+        # what two interleaved half-batches would give at this lane count (kernel tails overlap; per-kernel timings are
+        # then contended, which is why the headline leg runs one stream)
+        os.environ["RBL_PARTS"] = "2"
+        tdt, tunits, _, _, _, _ = run_leg(a.lanes, 2, 3, 0, False)
+        del os.environ["RBL_PARTS"]
+        two_streams = {"value": tunits / tdt, "note": "RBL_PARTS=2, 2 warm-up + 3 timed epochs"}
     if world == 1 and not a.no_extra_legs:
         if a.lanes != 4096:
             ldt, lunits, _, _, _, _ = run_leg(4096, 2, 3, 0, False)
@@ -261,6 +269,8 @@ def main():
             out["standalone_leg"] = {k: standalone[k] for k in ("value_serial", "note")}
         if lanes4096:
             out["lanes_4096"] = lanes4096
+        if two_streams:
+            out["two_streams"] = two_streams
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
             if out["cpu_baseline"].get("value"):

@@ -59,11 +59,11 @@ void Engine::construct() {
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream2_, hipStreamNonBlocking));
   for (int i = 0; i < 2; ++i) RBL_HIP_CHECK(hipStreamCreateWithFlags(&stream_x_[i], hipStreamNonBlocking));
-  // Lane parts on separate streams: with >= 8192 lanes the launches are long enough that one stream (net forward over all
-  // lanes, then the CFR step over all lanes) loses only ~3 % to kernel tails and launch gaps, and every kernel then runs
-  // with the GPU to itself (measured durations are the kernels' own); smaller batches gain 5-8 % from two interleaved
-  // half-batches whose tails overlap (bench numbers in DESIGN.md).
-  max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", max_lanes_ >= 8192 ? 1 : 2)));
+  // Lane parts on separate streams: with >= 16384 lanes the launches are long enough that one stream (net forward over
+  // all lanes, then the CFR step over all lanes) loses only ~3 % to kernel tails and launch gaps, and every kernel then
+  // runs with the GPU to itself (measured durations are the kernels' own); smaller batches gain 5-7 % from two
+  // interleaved half-batches whose tails overlap (4096 lanes: 38.6 vs 36.3 M it/s, 8192: 42.4 vs 40.3).
+  max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", max_lanes_ >= 16384 ? 1 : 2)));
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
   split_min_lanes_ = env_int("RBL_SPLIT_MIN_LANES", 1024);
@@ -421,7 +421,7 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_lane_row_.upload(h_row_, stream_);
   d_lane_act_.upload(h_act_, stream_);
   d_beliefs_.upload(h_beliefs_, stream_);
-  // lane parts (parts_for: one below 8192-lane engines' threshold, see the constructor): independent lane sets on their
+  // lane parts (parts_for; one part from 16384 lanes on, see the constructor): independent lane sets on their
   // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
   part_lanes(B, part_lane_);
