@@ -179,14 +179,14 @@ def main():
         # what two interleaved half-batches would give at this lane count (kernel tails overlap; per-kernel timings are
         # then contended, which is why the headline leg runs one stream)
         os.environ["RBL_PARTS"] = "2"
-        tdt, tunits, _, _, _, _ = run_leg(a.lanes, 2, 3, 0, False)
+        tdt, tunits, _, _, _, _ = run_leg(a.lanes, a.warmup, a.steps, 0, False)
         del os.environ["RBL_PARTS"]
-        two_streams = {"value": tunits / tdt, "note": "RBL_PARTS=2, 2 warm-up + 3 timed epochs"}
+        two_streams = {"value": tunits / tdt, "note": "RBL_PARTS=2, same warm-up and timed epochs as the headline leg"}
     if world == 1 and not a.no_extra_legs:
         if a.lanes != 4096:
-            ldt, lunits, _, _, _, _ = run_leg(4096, 2, 3, 0, False)
-            lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count), 2 warm-up + "
-                         "3 timed epochs"}
+            ldt, lunits, _, _, _, _ = run_leg(4096, a.warmup, a.steps, 0, False)
+            lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
+                         "streams), same warm-up and timed epochs as the headline leg"}
 
     def pmc_traffic(kernel_key):
         """HBM-side bytes per launch of `kernel_key` from the newest committed PMC summary (scripts/collect_profiles.sh)."""
