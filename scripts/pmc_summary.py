@@ -48,6 +48,25 @@ if kt:
             w.writerow([n, len(v), sum(v), round(sum(v) / len(v), 1), round(100 * sum(v) / tot, 2), min(v), max(v),
                         round(statistics.pstdev(v), 1)])
             out["kernels"].setdefault(n, {}).update(calls=len(v), avg_ns=sum(v) / len(v))
+# the bench times only the epochs after its warm-up: the same average restricted to those launches (the first
+# warmup / (warmup + steps) of a hot kernel's launches belong to the untimed, root-heavy warm-up epochs)
+try:
+    bj = json.load(open(os.path.join(base, "bench_under_rocprof.json")))
+    wu, st = int(bj["warmup"]), int(bj["steps"])
+    d2 = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        d2[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    lines = ["kernel,launches_all,avg_ns_all,launches_timed_epochs,avg_ns_timed_epochs,bench_hip_event_avg_ns"]
+    for key, field in (("mlp_resident_kernel", "roofline"), ("cfr_wave_kernel", "roofline_cfr"), ("cfr_rows_kernel", "roofline_cfr")):
+        for n, v in d2.items():
+            if key in n and len(v) % (wu + st) == 0 and len(v) >= 64:
+                v.sort()
+                timed = [x[1] for x in v[len(v) * wu // (wu + st):]]
+                lines.append(f"{n},{len(v)},{sum(x[1] for x in v) / len(v):.1f},{len(timed)},{sum(timed) / len(timed):.1f},"
+                             f"{bj[field]['avg_launch_us'] * 1000:.1f}")
+    open(os.path.join(base, f"{tag}_kernel_stats_timed_epochs.csv"), "w").write("\n".join(lines) + "\n")
+except Exception as ex:  # summary only
+    print("timed-epoch stats skipped:", ex)
 for sub, cname, scale in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 1.0)):
     cc = find(sub, "counter_collection.csv")
     if not cc:
