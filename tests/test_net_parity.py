@@ -83,6 +83,21 @@ def test_mlp_fallback_kernel(monkeypatch):
     _check_mlp(1, 6, 256, 2, True, 5000)
 
 
+@pytest.mark.parametrize("d,f,use_ln,rows", [
+    (1, 6, True, 1472), (1, 6, True, 1), (1, 6, True, 31), (1, 6, True, 33), (1, 6, True, 65), (1, 6, True, 32 * 256 + 1),
+    (1, 6, True, 40001), (1, 6, False, 129), (1, 4, True, 700), (1, 5, True, 2500), (1, 5, False, 96)])
+def test_mlp_pipelined_kernel(monkeypatch, d, f, use_ln, rows):
+    """The software-pipelined 32x32x16 kernel (RBL_MLP_TILE=6, opt-in: net_pipe_kernel.hip): same tolerance, including
+    batches shorter than its pipeline depth (1-3 tiles), ragged last tiles and more tiles than CUs."""
+    monkeypatch.setenv("RBL_MLP_TILE", "6")
+    _check_mlp(d, f, 256, 2, use_ln, rows)
+
+
+def test_mlp_pipelined_kernel_vs_torch_cpu_golden(monkeypatch):
+    monkeypatch.setenv("RBL_MLP_TILE", "6")
+    test_net2_vs_torch_cpu_golden()
+
+
 def _check_mlp(d, f, hidden, layers_n, use_ln, rows):
     e = _engine(d, f)
     rng = np.random.default_rng(hidden + rows)
