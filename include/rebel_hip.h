@@ -122,6 +122,20 @@ int rbl_strategy_recursive(rbl_engine* e, int to_leaf, double* out);
  * the reference's solver-construction order) and contributes its sampling strategy.  root_only != 0: subgames below the
  * root are solved to the end of the game without the net (max_depth = 100000), on a helper engine of the same device. */
 int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, double* out);
+/* The same to-leaf recursion (recursive_solving.cc:76-134, use_sampling_strategy = false) followed by
+ * compute_exploitability2 (subgame_solving.cc:802-816, BRSolver::compute_br :316-358) WITHOUT the dense [N][H][A] strategy
+ * (241 GB for 2 dice x 6 faces, recursive_eval.cc:269-363): the full-tree strategy stays on the device, edge-indexed
+ * [N - 1][H] fp64, written level by level (every subgame of a level = a lane, engine params and net) and consumed in place
+ * by two level-synchronous best-response sweeps.  out[2] = the two players' exploitabilities (n_shards == 1).
+ * Sharding: the pseudo-leaves of the root subgame (the nodes at depth max_depth) are dealt to the n shards, largest
+ * subtree first; shard s follows only its own.  top_values (optional, [2][M][H], M = nodes of depth <= max_depth =
+ * rbl_unroll_tree(.., -1, 0, max_depth)) receives the best-response values of those nodes per traverser and top_owner
+ * (optional, int32[M]) the owning shard of every non-terminal depth-max_depth node (-1 elsewhere); the caller redoes the
+ * sweep over the top levels on the host with each depth-max_depth value taken from its owner; out = NaN if n > 1.
+ * stats (optional, double[8]): full-tree nodes, subgames solved, recursion levels, seconds in the recursion, seconds in
+ * the two sweeps, bytes of the device-resident strategy, frontier items followed, M. */
+int rbl_exploitability_recursive(rbl_engine* e, int shard, int n_shards, double out[2], double* top_values,
+                                 int32_t* top_owner, double* stats);
 /* compute_immediate_regrets (subgame_solving.cc:984-1050; printed by recursive_eval --print_regret[_summary],
  * recursive_eval.cc:28-53): strategies = n_strategies dense full-tree strategies [N_full][H][A] back to back; out[N_full][H] =
  * max over the actions of the regret accumulated over all strategies and both traversers, divided by n_strategies (0 on

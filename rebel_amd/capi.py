@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -121,6 +121,7 @@ def lib():
         "rbl_solver_get_queries": (C.c_int, [vp, fp]),
         "rbl_solver_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_net_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
+        "rbl_exploitability_recursive": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, i32p, dp]),
         "rbl_selfplay_create": (vp, [vp, C.c_int, i32p, C.c_double, C.c_int]),
         "rbl_selfplay_destroy": (None, [vp]),
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
@@ -184,6 +185,35 @@ def ev2(dice, faces, strategy1, strategy2, device=0):
     b = np.ascontiguousarray(strategy2, np.float64)
     out = np.zeros(2)
     _check(lib().rbl_ev2(device, dice, faces, _p(a, C.c_double), _p(b, C.c_double), _p(out, C.c_double)))
+    return out
+
+
+def combine_exploitability(dice, faces, max_depth, tops):
+    """Shards of rbl_exploitability_recursive -> the two exploitabilities.  tops[s] = (top_values, top_owner) of shard s.
+    BRSolver::compute_br (subgame_solving.cc:326-355) over the nodes of depth <= max_depth on the host: a non-terminal node
+    at depth max_depth takes its value from the shard that owns its subtree, a terminal from shard 0 (it depends on the
+    root subgame only, which every shard solves); above, the traverser's nodes take the first-then-strictly-greater
+    maximum over their children, the opponent's the sum in ascending order; then vector_sum / H (:813-814)."""
+    tree = unroll_tree(dice, faces, -1, 0, max_depth)
+    owner = tops[0][1]
+    H = tops[0][0].shape[2]
+    out = np.zeros(2)
+    for t in range(2):
+        val = np.array(tops[0][0][t], dtype=np.float64, copy=True)
+        for n in range(len(tree) - 1, -1, -1):
+            last_bid, player, cb, ce = (int(x) for x in tree[n][:4])
+            if cb == ce:
+                if owner[n] >= 0:
+                    val[n] = tops[owner[n]][0][t][n]
+                continue
+            v = val[cb].copy()
+            for c in range(cb + 1, ce):
+                v = np.where(val[c] > v, val[c], v) if player == t else v + val[c]
+            val[n] = v
+        s = 0.0
+        for x in val[0]:
+            s += x
+        out[t] = s / H
     return out
 
 
@@ -336,6 +366,21 @@ class Engine:
         out = np.zeros((n, self.H, self.A))
         _check(self.L.rbl_strategy_recursive_sampled(self.h, int(seed), int(root_only), _p(out, C.c_double)))
         return out
+
+    def exploitability_recursive(self, shard=0, n_shards=1, max_depth=None):
+        """rbl_exploitability_recursive: (exploitabilities[2], (top_values[2][M][H], top_owner[M]), stats dict); the
+        full-tree strategy never leaves the device.  max_depth = the engine's params.max_depth (sizes the top levels)."""
+        if max_depth is None:
+            max_depth = self.params.max_depth
+        M = len(unroll_tree(self.dice, self.faces, -1, 0, max_depth))
+        out = np.zeros(2)
+        tv = np.zeros((2, M, self.H))
+        own = np.full(M, -1, np.int32)
+        st = np.zeros(8)
+        _check(self.L.rbl_exploitability_recursive(self.h, int(shard), int(n_shards), _p(out, C.c_double),
+                                                   _p(tv, C.c_double), _p(own, C.c_int32), _p(st, C.c_double)))
+        keys = ("nodes", "subgames", "levels", "solve_s", "sweep_s", "strategy_bytes", "frontier_items", "top_nodes")
+        return out, (tv, own), dict(zip(keys, st))
 
     def hand_values(self, lane, player):
         out = np.zeros(self.H)

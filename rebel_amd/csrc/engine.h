@@ -103,6 +103,19 @@ class Engine {
     return DeviceLanes{d_lane_shape_.p, d_lane_player_.p, d_lane_row_.p, d_lane_act_.p, d_beliefs_.p, d_snapshot_.p,
                        d_root_mean_.p, d_shape_epar_.p};
   }
+  // read-only view of the solver state for the streaming evaluation (eval_stream.hip); valid until the next reset()
+  struct EvalView {
+    const double *sums, *sigma, *beliefs;
+    const int *lane_shape, *lane_player;
+    const ShapeDev* shapes;
+    const int *parent, *cb, *ce, *depth, *leaves;
+    int num_steps[2];
+    bool use_cfr;
+  };
+  EvalView eval_view() const {
+    return EvalView{d_sums_.p,   d_sigma_.p, d_beliefs_.p, d_lane_shape_.p, d_lane_player_.p, d_shapes_.p, d_parent_.p,
+                    d_cb_.p,     d_ce_.p,    d_depth_.p,   d_leaves_.p,     {num_steps_[0], num_steps_[1]}, p_.use_cfr != 0};
+  }
   const ShapeDev* shapes_dev() const { return d_shapes_.p; }
   const int* act_dev() const { return d_act_.p; }
   const int* cb_dev() const { return d_cb_.p; }
@@ -217,6 +230,11 @@ class Engine {
   rbl_kernel_stats stats_{};
   double step_bytes_[2] = {0, 0};  // algorithmic bytes of one CFR step per traverser, summed over lanes
 };
+
+// eval_stream.hip: compute_strategy_recursive_to_leaf + compute_exploitability2 with the full-tree strategy kept on the
+// device, edge-indexed (no dense [N][H][A] tabulation); see include/rebel_hip.h: rbl_exploitability_recursive
+void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
+                              double* stats);
 
 class SelfPlay {
  public:

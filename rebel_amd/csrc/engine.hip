@@ -1613,6 +1613,10 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
     }
   });
 }
+int rbl_exploitability_recursive(rbl_engine* e, int shard, int n_shards, double out[2], double* top_values,
+                                 int32_t* top_owner, double* stats) {
+  return guard([&] { rbl::exploitability_recursive(need(e), shard, n_shards, out, top_values, top_owner, stats); });
+}
 int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out) {
   return guard([&] { need(e).evaluate(traverser, out); });
 }

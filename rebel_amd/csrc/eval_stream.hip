@@ -1,0 +1,494 @@
+// rebel_amd/csrc/eval_stream.hip -- exploitability of the recursively solved full-tree strategy WITHOUT a dense tabulation.
+//
+// What it restates (BASELINE configs[4]: "2d x 6f ... + recursive_eval exploitability check"):
+//   compute_strategy_recursive_to_leaf, use_sampling_strategy = false   /root/reference/csrc/liars_dice/recursive_solving.cc:76-134
+//   compute_exploitability2 / BRSolver::compute_br                       /root/reference/csrc/liars_dice/subgame_solving.cc:802-816, 316-358
+//   terminal values, reach sweep                                         subgame_solving.cc:80-98, 765-789, 54-78
+// The reference (and rbl_strategy_recursive + rbl_exploitability2, engine.hip) hold the full-tree strategy as a dense
+// [N][H][A] array: 241 GB for 2 dice x 6 faces (N = 33.5 M).  Here the strategy lives on the device, EDGE-indexed
+// [N - 1][H] fp64 (edge = child node - 1: 9.7 GB), is written level by level -- every subgame of a recursion level is a lane
+// of the engine; a scatter kernel copies the lanes' average strategies to their full-tree edges and builds the next level's
+// frontier (node ids + beliefs) on the device -- and is consumed in place by two level-synchronous best-response sweeps
+// (opponent reach top-down, values bottom-up).  The full tree itself is two flat tables: last bid (1 byte) and first child
+// (4 bytes) per node in the reference's BFS order (tree.h:51-70); everything else follows from them.
+//
+// Arithmetic is the reference's, operation for operation (sequential sums in ascending child / hand order, the fp32
+// truncation of the win probability, first-child-then-strictly-greater maximum): on games small enough for both, the
+// result is bit-identical to the dense path and to the oracle (tests/test_eval_parity.py).  Compiled with -ffp-contract=off.
+//
+// Sharding (north_star: independent game batches per GPU).  Every shard solves the root subgame; its pseudo-leaves (the
+// nodes at depth max_depth) are dealt to the shards largest subtree first, each to the least loaded shard (subtrees
+// below one root ACTION cannot be balanced: the first bid's subtree is half of the game).  A shard then follows only its
+// own frontier and returns the best-response values of every node of depth <= max_depth together with the owner of each
+// depth-max_depth node; the caller redoes the sweep over those top levels on the host, taking each depth-max_depth
+// value from its owner (rebel_amd/capi.py: combine_exploitability) -- no device collective.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "engine.h"
+
+namespace rbl {
+
+namespace {
+
+constexpr double kEpsBelief = 1e-80;  // kReachSmoothingEps (subgame_solving.h)
+
+struct FullTree {                   // BFS order of tree.h:51-70; mover of a node = depth & 1
+  std::vector<int8_t> bid;          // last bid of the node (-1 at the root)
+  std::vector<int32_t> cb;          // first child (children are contiguous: one per legal action, ascending)
+  std::vector<int64_t> lev_off;     // node-id range of depth d is [lev_off[d], lev_off[d + 1])
+  int64_t N = 0;
+};
+
+FullTree build_full_tree(const Rules& g) {
+  if (g.A > 120) throw std::runtime_error("exploitability_recursive: more than 120 actions");
+  FullTree t;
+  // N = 2^A nodes for A actions (every increasing bid sequence, optionally closed by liar): refuse what cannot be held
+  if (g.A > 27) throw std::runtime_error("exploitability_recursive: full tree too large (2^" + std::to_string(g.A) + " nodes)");
+  t.bid.reserve((size_t)1 << g.A);
+  t.cb.reserve((size_t)1 << g.A);
+  t.bid.push_back(-1);
+  t.cb.push_back(0);
+  t.lev_off.push_back(0);
+  int64_t level_end = 1;
+  for (int64_t i = 0; i < (int64_t)t.bid.size(); ++i) {
+    if (i == level_end) {
+      t.lev_off.push_back(i);
+      level_end = (int64_t)t.bid.size();
+    }
+    const int b = t.bid[i];
+    if (b == g.liar) continue;
+    int lo, hi;
+    g.bid_range(b, &lo, &hi);
+    if ((int64_t)t.bid.size() + (hi - lo) > (int64_t)std::numeric_limits<int32_t>::max())
+      throw std::runtime_error("exploitability_recursive: node index overflow");
+    t.cb[i] = (int32_t)t.bid.size();
+    for (int a = lo; a < hi; ++a) {
+      t.bid.push_back((int8_t)a);
+      t.cb.push_back(0);
+    }
+  }
+  t.lev_off.push_back((int64_t)t.bid.size());
+  t.N = (int64_t)t.bid.size();
+  return t;
+}
+
+struct ScatterArgs {
+  // engine state
+  const double* src;  // sum_strategies (CFR) or the average strategy itself (FP), [lane][Emax * H]
+  int normalise;      // CFR: rows are sum_strategies, normalised on read (subgame_solving.cc:658-660)
+  int steps0, steps1; // num_steps per player (0: the mover's rows keep the uniform initialisation, :518-519)
+  int emax, H;
+  const int* lane_shape;
+  const int* lane_player;
+  const double* beliefs;  // [lane][2][H]
+  const ShapeDev* shapes;
+  const int *parent, *cb, *ce, *depth, *leaves;
+  // full tree
+  const int32_t* f_cb;
+  double* sigma_full;  // [N - 1][H]
+  // per lane of this batch
+  const int32_t* lane_node;  // full-tree node of the lane's root
+  const int64_t* lane_out;   // first slot of the lane's pseudo-leaves in the next frontier
+  const int32_t* lane_tag;   // index of the root subgame's pseudo-leaf the lane descends from (-1 at the root)
+  // next frontier
+  int32_t* nf_node;
+  int32_t* nf_tag;
+  double* nf_beliefs;  // [slot][2][H]
+};
+
+// One workgroup per lane: (1) full-tree ids of the subgame's nodes, (2) average strategy of every edge -> sigma_full and an
+// LDS image, (3) per pseudo-leaf and player the reach under that strategy, normalised (normalize_beliefs_inplace,
+// recursive_solving.cc:41-44) -> next frontier.
+__global__ void __launch_bounds__(256) scatter_strategy_kernel(const ScatterArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = blockIdx.x, H = a.H;
+  const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
+  const int N = sh.N, off = sh.node_off;
+  const int root_player = a.lane_player[lane];
+  double* avg = reinterpret_cast<double*>(smem);                      // [N - 1][H]
+  int32_t* fid = reinterpret_cast<int32_t*>(avg + (size_t)a.emax * H);  // [N]
+  const double* src = a.src + (size_t)lane * a.emax * H;
+
+  if (threadIdx.x == 0) fid[0] = a.lane_node[lane];
+  __syncthreads();
+  for (int lev = 0; lev + 1 < sh.nlev; ++lev) {
+    for (int n = sh.lev_off[lev] + threadIdx.x; n < sh.lev_off[lev + 1]; n += blockDim.x) {
+      const int c0 = a.cb[off + n], c1 = a.ce[off + n];
+      if (c0 == c1) continue;
+      const int32_t base = a.f_cb[fid[n]];
+      for (int k = 0; k < c1 - c0; ++k) fid[c0 + k] = base + k;
+    }
+    __syncthreads();
+  }
+  // (2) one thread per (node with children, hand)
+  for (int i = threadIdx.x; i < N * H; i += blockDim.x) {
+    const int n = i / H, h = i - n * H;
+    const int c0 = a.cb[off + n], c1 = a.ce[off + n];
+    if (c0 == c1) continue;
+    const int mover = root_player ^ (a.depth[off + n] & 1);
+    const bool untouched = a.normalise && (mover == 0 ? a.steps0 : a.steps1) == 0;
+    double sum = 0;
+    if (a.normalise && !untouched)
+      for (int c = c0; c < c1; ++c) sum += src[(size_t)(c - 1) * H + h];
+    for (int c = c0; c < c1; ++c) {
+      double v = src[(size_t)(c - 1) * H + h];
+      if (untouched) v = 1. / (c1 - c0);
+      else if (a.normalise) v = v / sum;
+      avg[(size_t)(c - 1) * H + h] = v;
+      a.sigma_full[(size_t)(fid[c] - 1) * H + h] = v;
+    }
+  }
+  __syncthreads();
+  // (3) one thread per (pseudo-leaf, player)
+  for (int i = threadIdx.x; i < sh.L * 2; i += blockDim.x) {
+    const int k = i >> 1, pl = i & 1;
+    const int leaf = a.leaves[sh.leaf_off + k];
+    int path[kMaxLevels];  // nodes from the leaf up to (excluding) the root
+    int d = 0;
+    for (int n = leaf; n != 0; n = a.parent[off + n]) path[d++] = n;
+    const int64_t slot = a.lane_out[lane] + k;
+    double* out = a.nf_beliefs + ((size_t)slot * 2 + pl) * H;
+    const double* b = a.beliefs + ((size_t)lane * 2 + pl) * H;
+    double sum = 0;
+    for (int h = 0; h < H; ++h) {
+      double r = b[h];
+      for (int j = d - 1; j >= 0; --j) {  // root first: child_reaches *= strategy[node][hand][action] on the mover's nodes
+        const int n = path[j], p = a.parent[off + n];
+        if ((root_player ^ (a.depth[off + p] & 1)) == pl) r *= avg[(size_t)(n - 1) * H + h];
+      }
+      out[h] = r;
+      sum += r + kEpsBelief;
+    }
+    for (int h = 0; h < H; ++h) out[h] = (out[h] + kEpsBelief) / sum;
+    if (pl == 0) {
+      a.nf_node[slot] = fid[leaf];
+      // which pseudo-leaf of the ROOT subgame a frontier item descends from: inherited, or (root subgame) its own slot
+      a.nf_tag[slot] = a.lane_tag[lane] >= 0 ? a.lane_tag[lane] : (int32_t)slot;
+    }
+  }
+}
+
+struct SweepArgs {
+  const int8_t* f_bid;
+  const int32_t* f_cb;
+  const double* sigma_full;  // [N - 1][H]
+  double* reach;             // [N][H] opponent reach
+  double* val;               // [N][H] traverser values
+  const int8_t* matches;     // [faces][H]
+  int64_t n0, n1;            // node range of the level being processed
+  int H, A, faces, dice, liar;
+  int trav, level;           // traverser; depth of the nodes n0..n1
+};
+
+// opponent reach of the children of level `level` (precompute_reaches, subgame_solving.cc:54-78): thread per (node, hand)
+__global__ void br_reach_kernel(const SweepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = b < 0 ? a.A - 1 : a.A - 1 - b;  // bid_range: bids b + 1 .. A - 2, plus liar unless at the root
+  const int64_t c0 = a.f_cb[n];
+  const double up = a.reach[n * H + h];
+  const bool opp_moves = (a.level & 1) != a.trav;
+  for (int k = 0; k < cnt; ++k)
+    a.reach[(c0 + k) * H + h] = opp_moves ? up * a.sigma_full[(c0 + k - 1) * H + h] : up;
+}
+
+// values of level `level` from the values of level + 1 (compute_br, :326-355) and terminal payoffs (:80-98, 765-789)
+__global__ void br_value_kernel(const SweepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;  // terminals are valued from their parent, which knows the bid that was called
+  const int cnt = b < 0 ? a.A - 1 : a.A - 1 - b;
+  const int64_t c0 = a.f_cb[n];
+  const bool mine = (a.level & 1) == a.trav;
+  double x = 0.0;
+  for (int k = 0; k < cnt; ++k) {
+    double y;
+    if (b >= 0 && k == cnt - 1) {  // the liar child: terminal, bid `b` is checked; mover(z) = the player who did NOT call
+      const int qty = 1 + b / a.faces, face = b % a.faces;
+      const int8_t* m = a.matches + face * H;
+      const double* r = a.reach + (c0 + k) * H;
+      double bins[2 * 8 + 2];
+      const int nbins = 2 * a.dice + 1;
+      for (int q = 0; q < nbins; ++q) bins[q] = 0.0;
+      double s = 0;
+      for (int g = 0; g < H; ++g) {
+        bins[m[g]] += r[g];
+        s += r[g];
+      }
+      for (int q = nbins - 2; q >= 0; --q) bins[q] += bins[q + 1];
+      const int left = max(0, qty - (int)m[h]);
+      const float pwin = (float)bins[left];  // fp32 truncation (:785)
+      y = (double)pwin * 2 - s;
+      if (((a.level + 1) & 1) != a.trav) y *= -1.0;
+      a.val[(c0 + k) * H + h] = y;  // kept for the caller's host-side recombination of shards
+    } else {
+      y = a.val[(c0 + k) * H + h];
+    }
+    if (mine) {  // first child, then strictly greater (:336-344)
+      if (k == 0 || y > x) x = y;
+    } else {
+      x += y;
+    }
+  }
+  a.val[n * H + h] = x;
+}
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+// out2: exploitabilities of the two players (n_shards == 1, NaN otherwise).  top_values (optional): [2][M][H] best-response
+// values per traverser of the M nodes of depth <= max_depth (M = size of unroll_tree(game, root, max_depth)); top_owner
+// (optional): [M] shard that owns the subtree of each non-terminal depth-max_depth node, -1 for every other node.
+// stats (optional): [8] = {nodes, subgames solved, levels, solve s, sweep s, bytes of the strategy, frontier items, M}.
+void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
+                              double* stats) {
+  const Rules& g = e.rules();
+  const ShapeTables& tb = e.tables();
+  const int H = g.H, A = g.A;
+  if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("exploitability_recursive: bad shard");
+  if (g.dice > 8) throw std::runtime_error("exploitability_recursive: more than 8 dice");
+  RBL_HIP_CHECK(hipSetDevice(e.device()));
+  hipStream_t st = e.stream();
+  const int D = e.params().max_depth;
+  if (D < 1) throw std::runtime_error("exploitability_recursive: max_depth must be >= 1");
+  const size_t lds = (size_t)e.emax() * H * sizeof(double) + (size_t)tb.max_N * sizeof(int32_t);
+  if (lds > 160 * 1024)
+    throw std::runtime_error("exploitability_recursive: subgames of depth " + std::to_string(D) +
+                             " do not fit the scatter kernel's LDS image (" + std::to_string(lds) + " bytes)");
+  (void)hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+
+  const double t0 = now_s();
+  const FullTree ft = build_full_tree(g);
+  DevBuf<int8_t> d_bid, d_matches;
+  DevBuf<int32_t> d_cb, d_node[2], d_lane_node, d_tag[2], d_lane_tag;
+  DevBuf<int64_t> d_lane_out;
+  DevBuf<double> d_sigma, d_bel[2];
+  d_bid.upload(ft.bid, st);
+  d_cb.upload(ft.cb, st);
+  d_sigma.alloc((size_t)std::max<int64_t>(1, ft.N - 1) * H);
+  RBL_HIP_CHECK(hipMemsetAsync(d_sigma.p, 0, d_sigma.n * sizeof(double), st));
+  {
+    std::vector<int8_t> m((size_t)g.faces * H);
+    for (int f = 0; f < g.faces; ++f)
+      for (int h = 0; h < H; ++h) m[(size_t)f * H + h] = (int8_t)g.matches(h, f);
+    d_matches.upload(m, st);
+  }
+
+  // ------------------------------------------------------------------ recursion, level by level
+  std::vector<int32_t> f_node{0};
+  std::vector<int32_t> f_tag{-1};
+  std::vector<int32_t> owner_of_tag;  // shard of each pseudo-leaf of the root subgame
+  d_bel[0].alloc(2 * (size_t)H);
+  {
+    std::vector<double> b(2 * (size_t)H, 1.0 / H);  // get_initial_beliefs
+    d_bel[0].upload(b, st);
+  }
+  int cur = 0, level = 0;
+  int64_t n_subgames = 0, n_owned = 0;
+  const int maxB = e.max_lanes();
+  std::vector<int32_t> bids(maxB), players(maxB), lane_node(maxB);
+  std::vector<int32_t> lane_tag(maxB);
+  std::vector<int64_t> lane_out(maxB);
+  std::vector<double> bel_host((size_t)maxB * 2 * H);
+  while (!f_node.empty()) {
+    const size_t count = f_node.size();
+    const int player = (int)(((int64_t)level * D) & 1);
+    // the frontier of the next level: every pseudo-leaf of every subgame of this level (a non-terminal node always has children)
+    std::vector<int64_t> out_off(count + 1, 0);
+    for (size_t i = 0; i < count; ++i) out_off[i + 1] = out_off[i] + tb.shapes[ft.bid[f_node[i]] + 1].L;
+    const int64_t next_count = out_off[count];
+    const int nxt = cur ^ 1;
+    d_node[nxt].alloc((size_t)std::max<int64_t>(1, next_count));
+    d_tag[nxt].alloc((size_t)std::max<int64_t>(1, next_count));
+    d_bel[nxt].alloc((size_t)std::max<int64_t>(1, next_count) * 2 * H);
+    for (size_t base = 0; base < count; base += maxB) {
+      const int B = (int)std::min<size_t>(maxB, count - base);
+      RBL_HIP_CHECK(hipMemcpyAsync(bel_host.data(), d_bel[cur].p + base * 2 * H, (size_t)B * 2 * H * sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+      RBL_HIP_CHECK(hipStreamSynchronize(st));
+      for (int i = 0; i < B; ++i) {
+        bids[i] = ft.bid[f_node[base + i]];
+        players[i] = player;
+        lane_node[i] = f_node[base + i];
+        lane_tag[i] = f_tag[base + i];
+        lane_out[i] = out_off[base + i];
+      }
+      e.reset(B, bids.data(), players.data(), bel_host.data(), nullptr);
+      e.multistep(-1);
+      e.sync();  // every lane part (stream) of the engine has finished before the scatter kernel reads the lanes
+      const Engine::EvalView v = e.eval_view();
+      d_lane_node.upload(std::vector<int32_t>(lane_node.begin(), lane_node.begin() + B), st);
+      d_lane_tag.upload(std::vector<int32_t>(lane_tag.begin(), lane_tag.begin() + B), st);
+      d_lane_out.upload(std::vector<int64_t>(lane_out.begin(), lane_out.begin() + B), st);
+      ScatterArgs a{};
+      a.src = v.use_cfr ? v.sums : v.sigma;
+      a.normalise = v.use_cfr ? 1 : 0;
+      a.steps0 = v.num_steps[0];
+      a.steps1 = v.num_steps[1];
+      a.emax = e.emax();
+      a.H = H;
+      a.lane_shape = v.lane_shape;
+      a.lane_player = v.lane_player;
+      a.beliefs = v.beliefs;
+      a.shapes = v.shapes;
+      a.parent = v.parent;
+      a.cb = v.cb;
+      a.ce = v.ce;
+      a.depth = v.depth;
+      a.leaves = v.leaves;
+      a.f_cb = d_cb.p;
+      a.sigma_full = d_sigma.p;
+      a.lane_node = d_lane_node.p;
+      a.lane_out = d_lane_out.p;
+      a.lane_tag = d_lane_tag.p;
+      a.nf_node = d_node[nxt].p;
+      a.nf_tag = d_tag[nxt].p;
+      a.nf_beliefs = d_bel[nxt].p;
+      hipLaunchKernelGGL(scatter_strategy_kernel, dim3(B), dim3(256), lds, st, a);
+      RBL_HIP_CHECK(hipGetLastError());
+      RBL_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above and the engine's lanes are reused next batch
+      n_subgames += B;
+    }
+    n_owned += (int64_t)count;
+    // next frontier: ids and tags back to the host (the beliefs stay on the device); a shard keeps its own root actions
+    std::vector<int32_t> nn((size_t)next_count);
+    std::vector<int32_t> nt((size_t)next_count);
+    if (next_count) {
+      RBL_HIP_CHECK(hipMemcpyAsync(nn.data(), d_node[nxt].p, (size_t)next_count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      RBL_HIP_CHECK(hipMemcpyAsync(nt.data(), d_tag[nxt].p, (size_t)next_count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      RBL_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (level == 0) {
+      // deal the root subgame's pseudo-leaves to the shards: largest subtree first (a node with last bid b heads
+      // 2^(liar - b) nodes), each to the least loaded shard; ties by index, so every shard computes the same map
+      owner_of_tag.assign((size_t)next_count, 0);
+      std::vector<int64_t> order((size_t)next_count);
+      for (int64_t i = 0; i < next_count; ++i) order[i] = i;
+      std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return ft.bid[nn[x]] < ft.bid[nn[y]]; });
+      std::vector<double> load(n_shards, 0.0);
+      for (int64_t i : order) {
+        int best = 0;
+        for (int sdx = 1; sdx < n_shards; ++sdx)
+          if (load[sdx] < load[best]) best = sdx;
+        owner_of_tag[(size_t)nt[i]] = best;
+        load[best] += std::ldexp(1.0, g.liar - ft.bid[nn[i]]);
+      }
+      if (top_owner) {
+        const int64_t M = (int64_t)ft.lev_off.size() - 1 > D ? ft.lev_off[D + 1] : ft.N;
+        for (int64_t i = 0; i < M; ++i) top_owner[i] = -1;
+        for (int64_t i = 0; i < next_count; ++i) top_owner[nn[i]] = owner_of_tag[(size_t)nt[i]];
+      }
+    }
+    if (n_shards > 1 && next_count) {  // compact the frontier (ids, tags and beliefs) to the items this shard owns
+      std::vector<int64_t> keep;
+      for (int64_t i = 0; i < next_count; ++i)
+        if (owner_of_tag[(size_t)nt[i]] == shard) keep.push_back(i);
+      DevBuf<double> compact;
+      compact.alloc(std::max<size_t>(1, keep.size()) * 2 * H);
+      // runs of consecutive kept slots are copied together
+      size_t w = 0;
+      for (size_t i = 0; i < keep.size();) {
+        size_t j = i + 1;
+        while (j < keep.size() && keep[j] == keep[j - 1] + 1) ++j;
+        RBL_HIP_CHECK(hipMemcpyAsync(compact.p + w * 2 * H, d_bel[nxt].p + (size_t)keep[i] * 2 * H,
+                                     (j - i) * 2 * H * sizeof(double), hipMemcpyDeviceToDevice, st));
+        w += j - i;
+        i = j;
+      }
+      RBL_HIP_CHECK(hipStreamSynchronize(st));
+      std::swap(d_bel[nxt].p, compact.p);
+      std::swap(d_bel[nxt].n, compact.n);
+      std::vector<int32_t> kn(keep.size());
+      std::vector<int32_t> kt(keep.size());
+      for (size_t i = 0; i < keep.size(); ++i) {
+        kn[i] = nn[keep[i]];
+        kt[i] = nt[keep[i]];
+      }
+      nn.swap(kn);
+      nt.swap(kt);
+    }
+    f_node.swap(nn);
+    f_tag.swap(nt);
+    cur = nxt;
+    ++level;
+  }
+  const double t1 = now_s();
+
+  // ------------------------------------------------------------------ best-response sweeps over the full tree
+  DevBuf<double> d_reach, d_val;
+  d_reach.alloc((size_t)ft.N * H);
+  d_val.alloc((size_t)ft.N * H);
+  const int nlev = (int)ft.lev_off.size() - 1;
+  std::vector<double> root(H);
+  const int64_t M = (int64_t)ft.lev_off.size() - 1 > D ? ft.lev_off[D + 1] : ft.N;  // nodes of depth <= max_depth
+  for (int t = 0; t < 2; ++t) {
+    std::vector<double> b(H, 1.0 / H);
+    RBL_HIP_CHECK(hipMemcpyAsync(d_reach.p, b.data(), H * sizeof(double), hipMemcpyHostToDevice, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    SweepArgs a{};
+    a.f_bid = d_bid.p;
+    a.f_cb = d_cb.p;
+    a.sigma_full = d_sigma.p;
+    a.reach = d_reach.p;
+    a.val = d_val.p;
+    a.matches = d_matches.p;
+    a.H = H;
+    a.A = A;
+    a.faces = g.faces;
+    a.dice = g.dice;
+    a.liar = g.liar;
+    a.trav = t;
+    for (int lev = 0; lev + 1 < nlev; ++lev) {
+      a.n0 = ft.lev_off[lev];
+      a.n1 = ft.lev_off[lev + 1];
+      a.level = lev;
+      const int64_t work = (a.n1 - a.n0) * H;
+      hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    }
+    for (int lev = nlev - 2; lev >= 0; --lev) {
+      a.n0 = ft.lev_off[lev];
+      a.n1 = ft.lev_off[lev + 1];
+      a.level = lev;
+      const int64_t work = (a.n1 - a.n0) * H;
+      hipLaunchKernelGGL(br_value_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+    RBL_HIP_CHECK(hipMemcpyAsync(root.data(), d_val.p, H * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (top_values)
+      RBL_HIP_CHECK(hipMemcpyAsync(top_values + (size_t)t * M * H, d_val.p, (size_t)M * H * sizeof(double),
+                                   hipMemcpyDeviceToHost, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    double s = 0;
+    for (int h = 0; h < H; ++h) s += root[h];  // vector_sum (util.h:87-90)
+    out2[t] = n_shards == 1 ? s / H : std::numeric_limits<double>::quiet_NaN();
+  }
+  const double t2 = now_s();
+  if (stats) {
+    stats[0] = (double)ft.N;
+    stats[1] = (double)n_subgames;
+    stats[2] = (double)level;
+    stats[3] = t1 - t0;
+    stats[4] = t2 - t1;
+    stats[5] = (double)d_sigma.n * sizeof(double);
+    stats[6] = (double)n_owned;
+    stats[7] = (double)M;
+  }
+}
+
+}  // namespace rbl

@@ -71,6 +71,35 @@ def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port):
     assert np.array_equal(capi.exploitability2(d, f, got), port.exploitability2(d, f, want))
 
 
+@pytest.mark.parametrize("d,f,depth,iters,use_cfr,lanes", [
+    (1, 4, 2, 32, True, 64), (1, 4, 1, 10, True, 7), (1, 5, 2, 12, True, 48), (2, 2, 2, 20, True, 64), (1, 6, 2, 6, True, 512),
+    (1, 4, 2, 1, True, 64), (1, 4, 2, 16, False, 64), (1, 4, 3, 8, True, 32)])
+def test_streaming_exploitability_bit_exact(d, f, depth, iters, use_cfr, lanes, port):
+    """rbl_exploitability_recursive (eval_stream.hip): the to-leaf recursion + compute_exploitability2 with
+    the full-tree strategy device-resident and edge-indexed == the oracle's depth-first recursion + dense BR sweep, and ==
+    the engine's own dense path; sharded by root action and recombined on the host it is the same number again."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=iters, max_depth=depth, linear_update=True, use_cfr=use_cfr)
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=lanes)
+    e.set_net_synthetic()
+    got, top, stats = e.exploitability_recursive()
+    want_strategy = port.strategy_recursive(d, f, orc.make_params(**kw), to_leaf=True, net=orc.NET_SYNTHETIC)
+    want = port.exploitability2(d, f, want_strategy)
+    assert np.array_equal(got, want), (got, want)
+    assert np.array_equal(got, capi.exploitability2(d, f, e.strategy_recursive(to_leaf=True)))
+    assert stats["nodes"] == want_strategy.shape[0] and stats["subgames"] >= 1
+    assert stats["strategy_bytes"] == 8 * e.H * (stats["nodes"] - 1)
+    assert np.array_equal(capi.combine_exploitability(d, f, depth, [top]), got)
+    for n_shards in (2, 3, 8):
+        parts = [e.exploitability_recursive(s, n_shards) for s in range(n_shards)]
+        assert all(np.isnan(p[0]).all() for p in parts)
+        assert all(np.array_equal(p[1][1], top[1] if n_shards == 1 else parts[0][1][1]) for p in parts)  # one owner map
+        assert sum(p[2]["subgames"] for p in parts) == stats["subgames"] + (n_shards - 1)  # every shard solves the root
+        assert np.array_equal(capi.combine_exploitability(d, f, depth, [p[1] for p in parts]), got)
+
+
 @pytest.mark.parametrize("d,f,depth,iters,seed,root_only,use_cfr", [
     (1, 4, 2, 32, 0, False, True), (1, 4, 2, 33, 5, False, True), (1, 5, 2, 16, 1, False, True), (1, 4, 1, 12, 2, True, True),
     (1, 4, 2, 24, 3, True, True), (2, 2, 2, 20, 4, False, True), (1, 4, 2, 16, 6, False, False)])
