@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--cfr", action="store_true")
     ap.add_argument("--print_regret", action="store_true")
     ap.add_argument("--print_regret_summary", action="store_true")
+    ap.add_argument("--num_threads", type=int, default=10)  # accepted for command-line compatibility; lanes replace threads
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max_lanes", type=int, default=4096)
     a = ap.parse_args()
@@ -101,10 +102,10 @@ def main():
             eng.set_net_zero()
         else:
             from rebel_amd.models import mlp_weights_from_state_dict
+            import torch
             if a.net.endswith(".npz"):
-                sd = dict(np.load(a.net))
+                sd = {k: torch.from_numpy(v) for k, v in np.load(a.net).items()}
             else:
-                import torch
                 sd = torch.load(a.net, map_location="cpu")
             eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
         summed = reach_sum = None

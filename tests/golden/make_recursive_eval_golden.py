@@ -1,0 +1,61 @@
+"""Generates tests/golden/recursive_eval_1d4f.json (+ recursive_eval_net_1d4f.npz): stdout of the UNMODIFIED reference
+tool oracle/_ref/recursive_eval (csrc/liars_dice/recursive_eval.cc, built by oracle/Makefile `ref`) for
+  (a) --net zero --cfr                       (full-tree solve only: the tool cannot repeat with the zero net), and
+  (b) --net <TorchScript Net2, seed 1234> --mdp_depth 2 --num_repeats 4 --cfr
+on 1 die x 4 faces.  tests/test_eval_parity.py::test_recursive_eval_tool_vs_reference_binary runs scripts/recursive_eval.py
+with the same arguments and compares the XXX / YYY lines (scripts/eval_all.py:100-104 parses them).
+The reference tool loads a TorchScript net on "cuda" first (recursive_eval.cc:316, real_net.cc:130-132), so (b) needs a
+GPU: it was produced on the MI355X box by `gpurun -- python tests/golden/make_recursive_eval_golden.py gpurun_out` (the
+prebuilt oracle/_ref/recursive_eval travels with the snapshot) and the two files were copied from gpurun_out/ into
+tests/golden/.  usage: make_recursive_eval_golden.py [output dir, default tests/golden]"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from rebel_amd.models import Net2  # noqa: E402  (same state_dict keys as cfvpy/models.py:64-94)
+
+BIN = os.path.join(ROOT, "oracle", "_ref", "recursive_eval")
+COMMON = ["--num_dice", "1", "--num_faces", "4", "--cfr", "--mdp_depth", "2"]
+
+
+def run(args):
+    with tempfile.TemporaryDirectory() as tmp:  # the tool writes strategy.*.txt into its cwd
+        out = subprocess.run([BIN] + args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+    lines = out.splitlines()
+    xxx = json.loads([l for l in lines if l.startswith("XXX ")][0][4:])
+    yyy = json.loads([l for l in lines if l.startswith("YYY ")][0][4:])
+    return dict(args=args, xxx=xxx, yyy=yyy, stdout=lines)
+
+
+def main():
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.manual_seed(1234)
+    net = Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2)
+    with torch.no_grad():  # outputs of the size a trained net produces (the 0.01 initial scale would hide the net)
+        net.output.weight.data *= 30
+        net.output.bias.data *= 30
+    sd = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    np.savez(os.path.join(out_dir, "recursive_eval_net_1d4f.npz"), **sd)
+    with tempfile.TemporaryDirectory() as tmp:
+        pt = os.path.join(tmp, "net.pt")
+        torch.jit.script(net).save(pt)
+        golden = dict(
+            zero=run(COMMON + ["--subgame_iters", "256", "--net", "zero"]),
+            net=run(COMMON + ["--subgame_iters", "32", "--num_repeats", "4", "--num_threads", "1", "--net", pt]))
+    golden["net"]["args"][-1] = "tests/golden/recursive_eval_net_1d4f.npz"
+    golden["net"]["xxx"]["net"] = golden["net"]["yyy"]["net"] = "tests/golden/recursive_eval_net_1d4f.npz"
+    with open(os.path.join(out_dir, "recursive_eval_1d4f.json"), "w") as f:
+        json.dump(golden, f, indent=1)
+    print(json.dumps({k: dict(xxx=v["xxx"], yyy=v["yyy"]) for k, v in golden.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

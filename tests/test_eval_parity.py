@@ -163,6 +163,57 @@ def test_recursive_eval_tool(tmp_path):
     assert set(ev) == set(d) and abs(float(ev["full_tree"])) < 1e-6  # EV of the full-tree strategy against itself
 
 
+def test_recursive_eval_tool_vs_reference_binary():
+    """scripts/recursive_eval.py against the UNMODIFIED reference tool (oracle/_ref/recursive_eval = recursive_eval.cc built by
+    oracle/Makefile; golden stdout in tests/golden/recursive_eval_1d4f.json, made by make_recursive_eval_golden.py): the
+    XXX / YYY lines scripts/eval_all.py:100-104 parses.  Zero net (pure CFR, no value net anywhere): identical strings.
+    TorchScript Net2 with O(0.3) outputs, 4 sampled repeats of 32 iterations: the 6-decimal numbers to 2e-5 (measured 7e-6; the MFMA
+    forward and torch's differ by ~1e-7 per call, which CFR amplifies: DESIGN.md section 5, P3)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = json.load(open(os.path.join(root, "tests", "golden", "recursive_eval_1d4f.json")))
+    for case, tol in (("zero", 0.0), ("net", 2e-5)):  # measured on MI355X: max 7e-6
+        g = golden[case]
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py")] + g["args"], cwd=root,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:]
+        lines = out.stdout.splitlines()
+        for tag in ("XXX", "YYY"):
+            got = json.loads([l for l in lines if l.startswith(tag + " ")][0][4:])
+            want = g[tag.lower()]
+            assert list(got) == list(want), (got, want)
+            for k in want:
+                if k == "net":
+                    continue
+                if tol == 0.0:
+                    assert got[k] == want[k], (case, tag, k, got[k], want[k])
+                else:
+                    print(f"[recursive_eval vs reference] {case} {tag} {k}: ours {got[k]} reference {want[k]}")
+                    assert abs(float(got[k]) - float(want[k])) <= tol, (case, tag, k, got[k], want[k])
+        if case == "zero":  # the exploitability trace of the full-tree solve, line for line
+            want_iter = [l for l in g["stdout"] if l.startswith("Iter=") or l.startswith("Full FP")]
+            got_iter = [l for l in lines if l.startswith("Iter=") or l.startswith("Full FP")]
+            assert got_iter == want_iter
+
+
+def test_streaming_exploitability_2d6f_full_tree():
+    """BASELINE configs[4] at full size: 2 dice x 6 faces, 33 554 431 nodes, strategy edge-indexed on the device (9.7 GB);
+    two iterations per subgame keep it a few seconds.  Sanity of the numbers + two shards recombined == unsharded."""
+    from rebel_amd import capi
+
+    e = capi.Engine(2, 6, capi.make_params(num_iters=2, max_depth=2, linear_update=True, use_cfr=True), max_lanes=8192)
+    e.set_net_synthetic()
+    got, top, stats = e.exploitability_recursive()
+    assert stats["nodes"] == 2 ** 25 - 1 and stats["subgames"] == 2 ** 23 and stats["levels"] == 13
+    assert np.isfinite(got).all() and -1.0 <= got.min() and got.max() <= 1.0 and got.sum() >= 0
+    parts = [e.exploitability_recursive(s, 2) for s in range(2)]
+    assert np.array_equal(capi.combine_exploitability(2, 6, 2, [p[1] for p in parts]), got)
+
+
 def test_immediate_regrets_bit_exact(port):
     """rbl_immediate_regrets (compute_immediate_regrets, subgame_solving.cc:984-1050; recursive_eval's --print_regret
     reports): plain-CFR regret updates of a full-tree solver on the device, against the oracle (pinned to the compiled
