@@ -157,7 +157,7 @@ def main():
 
     standalone = lanes4096 = None
     parts_env = os.environ.get("RBL_PARTS")
-    streams = int(parts_env) if parts_env else (1 if a.lanes >= 16384 else 2)  # the engine's default (engine.hip)
+    streams = int(st["n_streams"])  # what the engine ran (rbl_engine_stats), not what the environment suggests
     if world == 1 and not a.no_extra_legs and streams > 1:
         # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
         os.environ["RBL_PARTS"] = "1"
@@ -226,17 +226,19 @@ def main():
             "dtype": "f64 CFR state; value net f32 in/out, GEMMs as f16x2-split MFMA (3 f16 products per multiply, "
                      "f32 accumulate, 4e-7 max error vs float64), f32 LayerNorm/GELU",
             "data": "synthetic (self-play from the root state, random-init Net2 seed 0, lane seeds rank*lanes+i)",
-            "config": {"workload": f"{a.dice}dx{a.faces}f self-play data generation, subgame_iters={a.iters}, "
-                                   f"max_depth=2, linear CFR, sample_leaf, random_action_prob=0.25, {a.lanes} concurrent "
-                                   f"lanes per GPU, Net2(n_hidden=256,n_layers=2,layer_norm) batched forward on MFMA",
-                       "lanes_per_gpu": a.lanes, "subgame_iters": a.iters, "parallelism": f"independent lane sets x{world}"},
+            # short on purpose: the driver keeps the first ~120 characters (the lane count has to survive the cut)
+            "config": {"workload": f"{a.dice}dx{a.faces}f self-play, {a.lanes} lanes/GPU, subgame_iters={a.iters}, depth 2, "
+                                   f"linear CFR, Net2 256x2+LN on MFMA",
+                       "detail": "RlRunner::step per lane: sample_leaf, random_action_prob=0.25; every lane one subgame per step",
+                       "lanes_per_gpu": a.lanes, "subgame_iters": a.iters, "parallelism": f"independent lane sets x{world}",
+                       "lanes_note": "16 384 lanes since round 2 (BENCH_r01 ran 4 096: see lanes_4096 for that size)"},
             "games_per_s": games_all / dt_max,
             "examples_per_s": n_examples * world / dt_max,
             # achieved = ALGORITHMIC flops 2*rows*(Q*256 + 256*256 + 256*H) per launch / mean launch time; the kernel issues
             # 3 f16 MFMA products per multiply on padded tiles (K 27->32, H 6->16): 3.16x this on the matrix pipe.  On
             # gfx950 the f16 MFMA pipe and f32 FMA-class VALU work do not overlap (scripts/micro/), and the LayerNorm +
             # erf-GELU epilogue on 512 activations per row costs about as many issue cycles as the MFMAs: see DESIGN.md
-            "roofline": {"kernel": "mlp_resident_kernel<1,true> (f16x2-split MFMA, register-resident weights)", "bound": "mfma", "achieved": net_tf,
+            "roofline": {"kernel": capi.NET_KERNEL_NAMES.get(st["net_kernel"], str(st["net_kernel"])), "bound": "mfma", "achieved": net_tf,
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F16_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
                          "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),
@@ -247,8 +249,8 @@ def main():
                                      "in-mix: HIP events on the launch's own stream, the other stream's CFR kernel active",
                          "issued_mfma_tflops": net_tf * issued_ratio,
                          "vs_f32_mfma_peak": net_tf / MFMA_F32_PEAK_TFLOPS},
-            "roofline_cfr": {"kernel": "cfr_wave_kernel (one wavefront per lane)" if os.environ.get("RBL_CFR_WAVE", "1") != "0" and
-                             (a.dice, a.faces) in ((1, 6), (1, 4), (1, 5), (2, 3)) else "cfr_rows_kernel", "bound": "hbm", "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
+            "roofline_cfr": {"kernel": capi.CFR_KERNEL_NAMES.get(st["cfr_kernel"], str(st["cfr_kernel"])), "bound": "hbm",
+                             "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
                              "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"],
                              "algorithmic_bytes_per_launch": st["cfr_bytes"] / max(1, st["cfr_launches"]),
@@ -257,7 +259,7 @@ def main():
             "streams": streams,
             "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
         }
-        for key, kern in (("roofline", ("mlp_resident_kernel",)), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
+        for key, kern in (("roofline", ("mlp_resident_kernel", "mlp_pipe_kernel")), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
             tr = pmc_traffic(kern)
             if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
                 scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0

@@ -185,6 +185,11 @@ typedef struct {
   int64_t net_rows;                   /* rows pushed through the net by the timed launches */
   int64_t lane_steps;                 /* subgame-CFR-iterations executed (all launches, timed or not) */
   double cfr_bytes, net_flops;        /* algorithmic bytes / flops of the timed launches (per-lane shapes) */
+  /* what the engine actually launched last (reporting; not reset): CFR step kernel 0 generic (cfr_step_kernel), 1 one
+   * thread per tree row (cfr_rows_kernel), 2 one wavefront per lane (cfr_wave_kernel), 3 rows kernel with global state
+   * (2 dice x 6 faces); value-net kernel variant (MlpDev::tile: 6 pipelined, 5 register-resident, 3 feature split; 0 =
+   * no MLP net); number of lane parts = streams of the last batch */
+  int32_t cfr_kernel, net_kernel, n_streams, reserved;
 } rbl_kernel_stats;
 /* stride = 0: off; n > 0: bracket the CFR and net launches of every n-th iteration with HIP events */
 int rbl_engine_timing(rbl_engine* e, int stride);

@@ -51,7 +51,15 @@ class MlpWeights(C.Structure):
 class KernelStats(C.Structure):
     _fields_ = [("cfr_ms", C.c_double), ("net_ms", C.c_double), ("cfr_launches", C.c_int64),
                 ("net_launches", C.c_int64), ("net_rows", C.c_int64), ("lane_steps", C.c_int64),
-                ("cfr_bytes", C.c_double), ("net_flops", C.c_double)]
+                ("cfr_bytes", C.c_double), ("net_flops", C.c_double), ("cfr_kernel", C.c_int32), ("net_kernel", C.c_int32),
+                ("n_streams", C.c_int32), ("reserved", C.c_int32)]
+
+
+CFR_KERNEL_NAMES = {0: "cfr_step_kernel (generic)", 1: "cfr_rows_kernel (one thread per tree row)",
+                    2: "cfr_wave_kernel (one wavefront per lane)", 3: "cfr_rows_kernel<GS> (global state, 2dx6f)"}
+NET_KERNEL_NAMES = {0: "none", 3: "mlp_fsplit_forward_kernel (feature split)",
+                    5: "mlp_resident_kernel (f16x2-split MFMA, register-resident weights)",
+                    6: "mlp_pipe_kernel (f16x2-split MFMA 32x32x16, software-pipelined)"}
 
 
 def make_params(num_iters=10, max_depth=2, linear_update=False, use_cfr=False, optimistic=False, dcfr=False,

@@ -17,6 +17,10 @@
 // modes and big trees stay on the generic kernel (they share the global state layout).
 #include <type_traits>
 
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
 #include "cfr_kernels.h"
 
 namespace rbl {
@@ -566,13 +570,17 @@ bool cfr_rows_global_supported(int H, int A, int dice, int faces) { return H == 
 bool launch_cfr_rows_global(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream) {
   if (!(a.H == 36 && a.A == 25 && a.dice == 2)) return false;
   auto kern = cfr_rows_kernel<36, 25, 2, 6, true>;
-  static bool attr_set = false;  // more than 64 KB of dynamic LDS has to be requested explicitly
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-        hipSuccess)
-      (void)hipGetLastError();
-    attr_set = true;
-  }
+  // more than 64 KB of dynamic LDS has to be requested explicitly -- per DEVICE (one engine and driver thread per GPU in
+  // the trainer's in-process topology), once, and a refusal is an error, not something to swallow
+  static std::once_flag attr_once[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) throw std::runtime_error("cfr_rows_global: no current device");
+  hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once[dev], [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_err != hipSuccess)
+    throw std::runtime_error(std::string("cfr_rows_global: cannot request 160 KB of LDS: ") + hipGetErrorString(attr_err));
   hipLaunchKernelGGL(kern, dim3(B), dim3(256), lds_bytes, stream, a);
   return true;
 }

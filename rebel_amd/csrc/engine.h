@@ -228,6 +228,7 @@ class Engine {
   std::vector<Pending> pending_;
   size_t ev_used_ = 0;
   rbl_kernel_stats stats_{};
+  int last_cfr_kernel_ = 0;  // which CFR step kernel the last step launch used (rbl_kernel_stats::cfr_kernel)
   double step_bytes_[2] = {0, 0};  // algorithmic bytes of one CFR step per traverser, summed over lanes
 };
 

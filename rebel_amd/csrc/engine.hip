@@ -367,6 +367,9 @@ void Engine::stats(rbl_kernel_stats* out, bool reset) {
   }
   pending_.clear();
   ev_used_ = 0;
+  stats_.cfr_kernel = last_cfr_kernel_;
+  stats_.net_kernel = net_mode_ == NetMode::kMlp ? mlp_.tile : 0;
+  stats_.n_streams = n_parts_;
   if (out) *out = stats_;
   if (reset) stats_ = rbl_kernel_stats{};
 }
@@ -612,10 +615,17 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     a.lane0 = l0;
     const bool is_step = mode == kModeStep || mode == kModeFpStep;
     if (is_step) time_begin(0, st);
+    int which = 0;
     if (mode == kModeStep && wave_ok_ && launch_cfr_wave(a, cnt, wave_lds_bytes_, st)) {
+      which = 2;
     } else if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
-    } else if (!(mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)))
+      which = 3;
+    } else if (mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)) {
+      which = 1;
+    } else {
       launch_cfr(a, cnt, block_, lds_bytes_, st);
+    }
+    if (is_step) last_cfr_kernel_ = which;
     if (is_step) time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
     if (is_step) {
@@ -1292,10 +1302,13 @@ void SelfPlay::init_device() {
     mt19937_seed_state((uint32_t)seeds_[i], one.data());  // std::mt19937(seed): seed taken modulo 2^32
     for (int k = 0; k < 624; ++k) mt[(size_t)k * n_ + i] = one[k];
   }
+  // the staging vectors are named locals that live until the stream synchronisation below: an asynchronous copy from
+  // pageable memory is host-synchronous in today's runtime, but the HIP API does not promise that
+  const std::vector<int> mt_idx(n_, 624), bid0(bid_.begin(), bid_.end()), player0(player_.begin(), player_.end());
   d_mt_.upload(mt, st);
-  d_mt_idx_.upload(std::vector<int>(n_, 624), st);
-  d_bid_.upload(std::vector<int>(bid_.begin(), bid_.end()), st);
-  d_player_.upload(std::vector<int>(player_.begin(), player_.end()), st);
+  d_mt_idx_.upload(mt_idx, st);
+  d_bid_.upload(bid0, st);
+  d_player_.upload(player0, st);
   d_sp_beliefs_.upload(beliefs_, st);
   d_ex_q_.alloc((size_t)2 * n_ * Q);
   d_ex_v_.alloc((size_t)2 * n_ * H);

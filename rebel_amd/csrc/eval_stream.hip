@@ -271,7 +271,7 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
   if (lds > 160 * 1024)
     throw std::runtime_error("exploitability_recursive: subgames of depth " + std::to_string(D) +
                              " do not fit the scatter kernel's LDS image (" + std::to_string(lds) + " bytes)");
-  (void)hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  RBL_HIP_CHECK(hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
   const double t0 = now_s();
   const FullTree ft = build_full_tree(g);

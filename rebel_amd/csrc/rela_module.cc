@@ -22,6 +22,7 @@
 #include <pybind11/stl.h>
 #include <torch/extension.h>
 #include <torch/script.h>
+#include <c10/hip/HIPStream.h>
 
 #include <atomic>
 #include <chrono>
@@ -43,6 +44,11 @@
 #include <vector>
 
 #include "../../include/rebel_hip.h"
+
+// Waits for the work this thread has queued on torch's CURRENT stream of `device` -- not for the whole device: a second
+// engine on the same GPU (two ModelLockers per device, or the trainer sharing the generating GPU) keeps whole epochs of
+// kernels in flight on its own stream, and a device-wide synchronisation would stall the caller behind all of them.
+static inline void sync_current_stream(int device) { c10::hip::getCurrentHIPStream((c10::DeviceIndex)device).synchronize(); }
 
 namespace py = pybind11;
 
@@ -283,7 +289,7 @@ class ValuePrioritizedReplay {
     auto w = data[2].to(torch::kCPU, torch::kFloat32).contiguous();
     if (q.dim() != 2 || v.dim() != 2 || w.dim() != 1 || q.size(0) != v.size(0) || q.size(0) != w.size(0))
       fail("replay.push: shapes must be [n,Q], [n,V], [n]");
-    if (on_gpu) torch::cuda::synchronize(q.device().index());  // the copies below read the tensors through raw pointers
+    if (on_gpu) sync_current_stream(q.device().index());  // the copies below read the tensors through raw pointers
     const int dev = on_gpu ? (int)q.device().index() : -1;     // device tensors go into the device ring without a host hop
     const int64_t n = q.size(0), chunk = std::max<int64_t>(1, ring_ - capacity_);
     for (int64_t s = 0; s < n; s += chunk) {
@@ -334,9 +340,11 @@ class ValuePrioritizedReplay {
         tv.narrow(0, 0, n - first).copy_(sv.narrow(0, first, n - first));
       }
       // the rows must be in place before they are published, and the source buffer is reused by the next epoch
-      if (tq.device().is_cuda()) torch::cuda::synchronize(tq.device().index());
+      // (the copies above were queued on this thread's current stream of the ring's device and, for a cross-device block,
+      // of the source device: those two streams are waited for, nothing else)
+      if (tq.device().is_cuda()) sync_current_stream(tq.device().index());
       if (device_index >= 0 && !(tq.device().is_cuda() && tq.device().index() == device_index))
-        torch::cuda::synchronize(device_index);
+        sync_current_stream(device_index);
     }
     for (int64_t i = 0; i < n; ++i) {
       const int j = (int)((start + i) % ring_);
@@ -356,8 +364,16 @@ class ValuePrioritizedReplay {
     return true;
   }
 
-  void ensure_layout(int64_t Q, int64_t V, int device_index) {  // m_ held
+  // Where the rings live (m_ held).  Default: on the GPU of the first engine that appends a device block -- in the trainer's
+  // topology (cfvpy/selfplay.py:193-252: cuda:0 trains, cuda:1.. generate, ONE replay) that is cuda:1; the other generators
+  // append with peer copies over xGMI (16 MB per epoch of 16 384 lanes) and sample(batch, "cuda:0") gathers on the ring's GPU
+  // and moves only the batch.  REBEL_AMD_REPLAY_DEVICE=<index> homes the rings on a chosen GPU instead (e.g. 0, the
+  // training GPU: sampling becomes local, every append a peer copy); REBEL_AMD_REPLAY_HOST=1 keeps them in host memory.
+  void ensure_layout(int64_t Q, int64_t V, int device_index) {
     const bool want_gpu = device_index >= 0 && !std::getenv("REBEL_AMD_REPLAY_HOST");
+    if (want_gpu)
+      if (const char* home = std::getenv("REBEL_AMD_REPLAY_DEVICE"))
+        if (*home) device_index = std::atoi(home);
     if (Q_ < 0) {
       Q_ = Q;
       V_ = V;
@@ -691,7 +707,7 @@ class ModelLocker {
     auto ot = torch::from_blob(out, {rows, n_out}, opt);
     std::vector<torch::jit::IValue> inputs = {qt};
     ot.copy_(self->jit_->forward(inputs).toTensor().to(torch::kFloat32));
-    torch::cuda::synchronize(self->device_index);
+    sync_current_stream(self->device_index);  // the engine's stream resumes once the values are in place
   }
 
   void apply(rbl_engine* e) {  // m_ held
@@ -699,6 +715,18 @@ class ModelLocker {
       if (apply_mlp(e, mlp_) == 0) return;
       // shape outside the fused kernel's envelope (e.g. n_hidden=512): fall through to the TorchScript forward
       jit_ = py_models_[0].attr("_c").cast<torch::jit::Module*>();
+      generic_reason_ = std::string("Net2 shape outside the MFMA forward's envelope (n_hidden = 256, n_in <= 128, n_out <= 64): ") +
+                        rbl_last_error();
+    }
+    {
+      static std::once_flag warned;  // the slow path is legitimate, but nobody should be on it without knowing
+      std::call_once(warned, [&] {
+        std::fprintf(stderr,
+                     "[rebel_amd.rela] ModelLocker: value net runs through the caller's TorchScript module on the GPU, not "
+                     "the fused MFMA forward (%s).  Device-resident epochs are off for these lanes: host-side tree walk, one "
+                     "stream synchronisation per CFR iteration -- expect several times lower throughput (INTEGRATION.md).\n",
+                     generic_reason_.empty() ? "module is not a Net2-shaped MLP" : generic_reason_.c_str());
+      });
     }
     // synchronous device-pointer callback: the engine stream is idle while libtorch runs (engine syncs around it)
     check(rbl_engine_set_net_callback(e, &ModelLocker::jit_forward, this, /*host_buffers=*/0), "set_net_callback");

@@ -8,11 +8,15 @@ def lane_seeds(rank, lanes_per_gpu):
     return [rank * lanes_per_gpu + i for i in range(lanes_per_gpu)]
 
 
-def reduce_job(dist, world, dt, units, games, device="cuda"):
-    """-> (max over ranks of dt, sum of units, sum of games)"""
+def reduce_job(dist, world, dt, units, games, device=None):
+    """-> (max over ranks of dt, sum of units, sum of games).  The scalars travel on the process group's own device: GPU
+    memory for RCCL ("nccl"), host memory for gloo (the CPU tests)."""
     if world <= 1:
         return dt, units, games
     import torch
+
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
 
     tot = torch.tensor([dt, units, games], dtype=torch.float64, device=device)
     mx = tot.clone()
