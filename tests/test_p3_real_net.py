@@ -9,7 +9,7 @@ beyond ~128 iterations, on the reference against itself too: SURVEY section 7). 
   * whole self-play trajectories at 128 iterations per subgame (default-init net): same public states, examples
     within 1e-5;
   * distribution-level agreement at 512 iterations with O(0.3) outputs, where individual strategies have long diverged:
-    root value means to 1e-2, game-length and example-value statistics within sampling error.
+    root value means to 6e-3 (measured 2.6e-3), game-length and example-value statistics within sampling error.
 """
 import numpy as np
 import pytest
@@ -49,7 +49,7 @@ def test_real_net_subgame_elementwise_through_128_iterations(port):
 
     d, f = 1, 6
     # (output scale, iterations through which sigma / average strategy agree to 1e-5, bound on the root values at 128)
-    for scale, exact_until, values_at_128 in ((1.0, 128, 1e-5), (30.0, 16, 5e-3)):
+    for scale, exact_until, values_at_128 in ((1.0, 128, 1e-5), (30.0, 16, 1.5e-3)):  # measured 3.7e-9 / 6.1e-4
         net = _net(d, f, scale)
         kw = dict(num_iters=128, max_depth=2, linear_update=True, use_cfr=True)
         e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=1)
@@ -64,8 +64,9 @@ def test_real_net_subgame_elementwise_through_128_iterations(port):
                 assert np.abs(e.get(0, capi.GET_AVERAGE) - o.get(orc.GET_AVERAGE)).max() <= 1e-5, (scale, it)
                 for pl in (0, 1):
                     assert np.abs(e.hand_values(0, pl) - o.hand_values(pl)).max() <= 1e-5, (scale, it, pl)
-        for pl in (0, 1):
-            assert np.abs(e.hand_values(0, pl) - o.hand_values(pl)).max() <= values_at_128, (scale, pl)
+        dv128 = max(np.abs(e.hand_values(0, pl) - o.hand_values(pl)).max() for pl in (0, 1))
+        print(f"P3 elementwise: output scale {scale}: max |d root values| at 128 iterations {dv128:.2e} (bound {values_at_128:.0e})")
+        assert dv128 <= values_at_128, (scale, dv128)
 
 
 def _gpu_games(d, f, net, iters, seeds, games):
@@ -121,8 +122,32 @@ def test_real_net_selfplay_trajectories_at_128_iterations(port):
     print(f"P3 @128: {same_path}/{2 * len(seeds)} games on the same public path; max |dquery| {dq:.2e}, max |dvalue| {dv:.2e}")
     # non-root subgames (peaked beliefs, O(0.3) values from the terminal payoffs) amplify sooner than the root subgame;
     # a policy difference flips a sampled action only when a draw lands inside it
-    assert same_path >= 0.9 * 2 * len(seeds), same_path
-    assert dq <= 1e-3 and dv <= 1e-2, (dq, dv)
+    # bounds = about twice the values measured on MI355X (48/48 games, 6.5e-4, 1.3e-3; printed above on every run)
+    assert same_path >= 2 * len(seeds) - 2, same_path
+    assert dq <= 1.5e-3 and dv <= 3e-3, (dq, dv)
+
+
+def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port):
+    """The same trajectory claim with the engine at BASELINE config 2's lane count (4 096 lanes = 8 300-row net launches on
+    every CU, two streams), Net2 instead of the synthetic net of test_selfplay_at_bench_size_vs_oracle: a sample of the
+    lanes against the oracle driven by torch-CPU Net2 (VERDICT r2 weak #1b)."""
+    d, f, iters = 1, 6, 128
+    net = _net(d, f, 1.0, seed=5)
+    seeds = list(range(5000, 5000 + 4096))
+    sample = list(range(0, 4096, 293))  # 14 lanes spread over both lane parts
+    gpu = _gpu_games(d, f, net, iters, seeds, 1)
+    ref = _oracle_games(port, d, f, net, iters, [seeds[i] for i in sample], 1)
+    same_path, dq, dv = 0, 0.0, 0.0
+    for i, r_lane in zip(sample, ref):
+        gg, rg = gpu[i][0], r_lane[0]
+        if len(gg) == len(rg) and all(np.array_equal(a[0][:2 + 13], b[0][:2 + 13]) for a, b in zip(gg, rg)):
+            same_path += 1
+            for (q, v), (rq, rv) in zip(gg, rg):
+                dq, dv = max(dq, np.abs(q - rq).max()), max(dv, np.abs(v - rv).max())
+    print(f"P3 @128, 4096 lanes: {same_path}/{len(sample)} sampled games on the same public path; max |dquery| {dq:.2e}, "
+          f"max |dvalue| {dv:.2e}")
+    assert same_path >= len(sample) - 1, same_path  # measured 14/14, 6.0e-7, 2.4e-7 (first games: mostly root subgames)
+    assert dq <= 1e-4 and dv <= 1e-4, (dq, dv)
 
 
 def test_real_net_selfplay_distribution_at_512_iterations(port):
@@ -137,7 +162,7 @@ def test_real_net_selfplay_distribution_at_512_iterations(port):
         for t in (0, 1):
             assert np.array_equal(gg[t][0], rg[t][0])  # identical root queries
             d0 = max(d0, np.abs(gg[t][1] - rg[t][1]).max())
-    assert d0 <= 1e-2, d0
+    assert d0 <= 6e-3, d0  # measured 2.6e-3
     # (2) game length (subgames per game) and example values: same distribution within sampling error
     lg, lr = np.array([len(g) / 2 for g in gpu]), np.array([len(g) / 2 for g in ref])
     se = np.sqrt((lg.var() + lr.var()) / len(seeds)) + 1e-9

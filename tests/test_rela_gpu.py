@@ -126,6 +126,53 @@ def test_generic_torchscript_module_runs_on_gpu():
     assert torch.isfinite(t.values).all() and t.values.abs().max() > 0
 
 
+def test_half_precision_model_through_model_locker():
+    """cfvpy/selfplay.py:211 builds the inference models with `half=cfg.half_inference` (model.half(), :42-43).  A scripted
+    half-precision Net2 goes through rela.ModelLocker like any other: its (half-rounded) weights are packed for the fused MFMA
+    forward, which computes in f32 -- the engine's values equal the f32 forward of those weights to 1e-5 and the GPU
+    half-precision forward of the same module to half precision."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd import capi
+    from rebel_amd.models import Net2, mlp_weights_from_state_dict
+
+    d, f = 1, 6
+    torch.manual_seed(11)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    with torch.no_grad():
+        net.output.weight *= 30
+        net.output.bias *= 30
+    half = torch.jit.script(net.half().to("cuda:0")).eval()
+    assert next(half.parameters()).dtype == torch.float16
+    locker = rela.ModelLocker([half], "cuda:0")
+    replay = rela.ValuePrioritizedReplay(capacity=1 << 14, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    ctx = rela.Context()
+    cfg = _cfg(rela, d, f, 16)
+    for i in range(64):
+        ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, i))
+    ctx.start()
+    _wait(lambda: replay.size() >= 256)
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    t, _ = replay.sample(128, "cpu")
+    assert torch.isfinite(t.values).all() and t.values.abs().max() > 1e-3
+    # the forward itself: engine (f32 arithmetic on the half-rounded weights) vs torch
+    sd32 = {k: v.float().cpu() for k, v in half.state_dict().items()}
+    e = capi.Engine(d, f, capi.make_params(num_iters=4, use_cfr=True))
+    e.set_net_mlp(*mlp_weights_from_state_dict(sd32))
+    q = t.query.numpy()
+    y = e.net_forward(q)
+    ref32 = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    ref32.load_state_dict(sd32)
+    with torch.no_grad():
+        want32 = ref32.double()(t.query.double()).numpy()
+        want16 = half(t.query.half().to("cuda:0")).float().cpu().numpy()
+    assert np.abs(y - want32).max() <= 1e-5
+    assert np.abs(y - want16).max() <= 2e-2 * max(1.0, np.abs(want32).max())
+
+
 def test_rela_lane_matches_capi_lane():
     """The examples a rela lane pushes are exactly those of the C-ABI self-play lane with the same seed."""
     import torch
