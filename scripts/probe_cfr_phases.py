@@ -2,7 +2,7 @@ import os, sys, numpy as np
 os.environ["RBL_CFR_DBG"] = "1"
 sys.path.insert(0, '.')
 from rebel_amd import capi
-B = 4096
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 e = capi.Engine(1, 6, capi.make_params(num_iters=1024, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
 e.set_net_synthetic()
 e.reset([-1]*B, [0]*B, np.full((B, 2, e.H), 1.0/e.H))
