@@ -31,6 +31,8 @@ struct CfrArgs {
   const int* irank;     // node -> index of its reach row (root / nodes with children), -1 otherwise (cfr_rows_kernel)
   const int* leaf_row;  // node -> net row within the lane for pseudo-leaves, -1 otherwise (cfr_rows_kernel)
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
+  const int8_t* wave_tabs;  // cfr_wave_kernel: per shape parent | act | cb | ce | depth | irank (N bytes each) | leaf nodes (L) |
+  const int* wave_tab_off;  //                  terminal nodes (T) as one 4-byte aligned blob; byte offset of each shape's blob
   int H, A, Q, faces, dice;
   int Emax, Nmax;         // per-lane strides: Emax*H reals per strategy array
   // ---- per-lane descriptors

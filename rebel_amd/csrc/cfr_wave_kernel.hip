@@ -74,7 +74,8 @@ template <int H, int A, int DICE, int FACES, int EHM, int LHM, int NM>
 __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
-  constexpr int KS = (EHM + W - 1) / W, KN = (NM + W - 1) / W;
+  constexpr int KS = (EHM + W - 1) / W;
+  constexpr int KT = ((7 * NM + LHM / H + 3) / 4 + W - 1) / W;  // dword strides of the byte-table blob (6 N + L + T bytes)
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x;
   typedef const int __attribute__((address_space(4)))* cint_p;
   typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
@@ -97,10 +98,10 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   double* val = sig + EH;            // [N][H]
   double* rho0 = val + N * H;        // [NI][H]
   double* rho1 = rho0 + NI * H;
-  double* ysum = rho1 + NI * H;      // [NI][H] regret-matching row sums
-  double* yrcp = ysum + NI * H;      // [NI][H] their refined reciprocals
+  // (the regret-matching row sums live in the value rows of the level they normalise, which are dead by then; their
+  // refined reciprocals are recomputed where they are used: 10.6 KB per root lane instead of 12.1 KB = 15 lanes per CU)
   // tree tables as bytes: every entry is a node id, an action, a row index or -1, all < 128 for these games (NM <= 127)
-  int8_t* tb = reinterpret_cast<int8_t*>(yrcp + NI * H);
+  int8_t* tb = reinterpret_cast<int8_t*>(rho1 + NI * H);
   int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
   int8_t *t_irank = tb + 5 * N, *t_leaf = tb + 6 * N, *t_term = t_leaf + L;  // t_leaf[k]: node of net row k; t_term[j]: j-th terminal
   int8_t* t_match = t_term + T;
@@ -159,26 +160,12 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     else
       load_sig(std::integral_constant<int, KS>{});
     // (the net's output rows go straight into the registers of the thread that will consume them: lv_ below)
-    const int* gp = a.parent + node_off + tid;
-    const int* ga = a.act + node_off + tid;
-    const int* gb = a.cb + node_off + tid;
-    const int* ge = a.ce + node_off + tid;
-    const int* gd = a.depth + node_off + tid;
-    const int* gi = a.irank + node_off + tid;
-    const int* gl = a.terms + shc->term_off + tid;
-    const int* gk = a.leaves + shc->leaf_off + tid;
-    int tp[KN], ta[KN], tcb[KN], tce[KN], td[KN], ti[KN], tl[KN], tk[KN];
+    // the lane's tree tables: one byte blob per shape in exactly the LDS layout (parent, act, cb, ce, depth, irank: N bytes
+    // each; leaf nodes: L; terminal nodes: T), copied dword-wise (was: eight int tables, 16 loads per thread, 4 bytes per entry)
+    const int* gt = reinterpret_cast<const int*>(a.wave_tabs + ((cint_p)a.wave_tab_off)[((cint_p)a.lane_shape)[lane]]) + tid;
+    int tw[KT];
 #pragma unroll
-    for (int u = 0; u < KN; ++u) {
-      tp[u] = gp[u * W];
-      ta[u] = ga[u * W];
-      tcb[u] = gb[u * W];
-      tce[u] = ge[u * W];
-      td[u] = gd[u * W];
-      ti[u] = gi[u * W];
-      tl[u] = gl[u * W];
-      tk[u] = gk[u * W];
-    }
+    for (int u = 0; u < KT; ++u) tw[u] = gt[u * W];
     const int8_t tm = a.matches[tid];
     if (tid < H) {
       bel_t = bel[t * H + tid];
@@ -200,12 +187,8 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       rho0[tid] = b0;
       rho1[tid] = b1;
     }
-    int8_t* const tabs[8] = {t_parent, t_act, t_cb, t_ce, t_depth, t_irank, t_leaf, t_term};
-    const int* const regs[8] = {tp, ta, tcb, tce, td, ti, tk, tl};
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-#pragma unroll
-      for (int u = 0; u < KN; ++u) tabs[k][tid + u * W] = (int8_t)regs[k][u];
+    for (int u = 0; u < KT; ++u) reinterpret_cast<int*>(tb)[tid + u * W] = tw[u];
     static_assert(NM <= 127, "byte tables");
     static_assert(FACES * H <= W, "match table staged by one store");
     t_match[tid] = tm;
@@ -390,7 +373,11 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       greg[i] = q * (q > 0 ? a.pos : a.neg);
     }
     wave_sync();
-    for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions, and their refined reciprocals
+    // the children's values have been consumed (regret update above): their rows now hold the row sums, one row per node
+    // of this level that has children (those nodes' reach-row ranks are consecutive; every one of them has >= 1 child)
+    double* ysum = val + c_lo * H;
+    const int irk0 = t_irank[n0];
+    for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
       if (c0 == c1) continue;
@@ -403,19 +390,21 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         if (c + 2 < c1) s += s2;
         if (c + 3 < c1) s += s3;
       }
-      const int ir = t_irank[n];
-      ysum[ir * H + h] = s;
-      yrcp[ir * H + h] = refine_rcp(s);
+      ysum[(t_irank[n] - irk0) * H + h] = s;
     }
     wave_sync();
 #pragma unroll
     for (int u = 0; u < KS; ++u) {
       const int i = tid + u * W;
-      if (i < ch) lsig[i] = div_by(lsig[i], ysum[pr[u]], yrcp[pr[u]]);
+      if (i < ch) {
+        const double s = ysum[pr[u] - irk0 * H];
+        lsig[i] = div_by(lsig[i], s, refine_rcp(s));
+      }
     }
     for (int i = tid + KS * W; i < ch; i += W) {
       const int ir = t_irank[t_parent[c_lo + i / H]], h = i % H;
-      lsig[i] = div_by(lsig[i], ysum[ir * H + h], yrcp[ir * H + h]);
+      const double s = ysum[(ir - irk0) * H + h];
+      lsig[i] = div_by(lsig[i], s, refine_rcp(s));
     }
     wave_sync();
   }
@@ -524,7 +513,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 }  // namespace
 
 size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
-  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)4 * NI * H;  // doubles
+  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)2 * NI * H;  // doubles
   const size_t b = d * 8 + (size_t)(6 * N + L + T) + (size_t)faces * H;
   return ((b + 15) & ~(size_t)15) + kWaveLdsSlack;
 }

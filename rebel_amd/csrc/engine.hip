@@ -105,6 +105,22 @@ void Engine::construct() {
   d_terms_.upload(padded(tabs_.terms), stream_);
   d_irank_.upload(padded(tabs_.irank), stream_);
   d_leaf_row_.upload(padded(tabs_.leaf_row), stream_);
+  {  // byte blobs of the per-shape tables in the one-wavefront kernel's LDS layout (staged with dword loads)
+    std::vector<int8_t> blob;
+    std::vector<int> off;
+    for (const ShapeDev& s : tabs_.shapes) {
+      while (blob.size() % 4) blob.push_back(0);
+      off.push_back((int)blob.size());
+      for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce, &tabs_.depth, &tabs_.irank})
+        for (int n = 0; n < s.N; ++n) blob.push_back((int8_t)(*tab)[s.node_off + n]);
+      for (int k = 0; k < s.L; ++k) blob.push_back((int8_t)tabs_.leaves[s.leaf_off + k]);
+      for (int k = 0; k < s.T; ++k) blob.push_back((int8_t)tabs_.terms[s.term_off + k]);
+    }
+    blob.resize(blob.size() + kWavePad, 0);
+    d_wave_tabs_.upload(blob, stream_);
+    d_wave_tab_off_.upload(off, stream_);
+    RBL_HIP_CHECK(hipStreamSynchronize(stream_));  // blob / off go out of scope
+  }
   std::vector<int8_t> m((size_t)g_.faces * g_.H + kWavePad);
   for (int f = 0; f < g_.faces; ++f)
     for (int h = 0; h < g_.H; ++h) m[(size_t)f * g_.H + h] = (int8_t)g_.matches(h, f);
@@ -574,6 +590,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.irank = d_irank_.p;
   a.leaf_row = d_leaf_row_.p;
   a.matches = d_matches_.p;
+  a.wave_tabs = d_wave_tabs_.p;
+  a.wave_tab_off = d_wave_tab_off_.p;
   a.H = g_.H;
   a.A = g_.A;
   a.Q = g_.query_size();

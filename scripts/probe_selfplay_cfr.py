@@ -4,7 +4,7 @@ import sys, time, numpy as np
 sys.path.insert(0, '.')
 from rebel_amd import capi
 from rebel_amd.sharding import lane_seeds
-B, iters = 4096, 1024
+B, iters = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096), 1024
 e = capi.Engine(1, 6, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
 e.set_net_synthetic()
 sp = capi.SelfPlay(e, lane_seeds(0, B), random_action_prob=0.25, sample_leaf=True)
