@@ -200,9 +200,13 @@ def main():
             for name, k in d.get("kernels", {}).items():
                 if any(key in name for key in kernel_key) and "fetch_size_bytes_per_launch" in k and \
                         "write_size_bytes_per_launch" in k:
-                    return {"bytes": k["fetch_size_bytes_per_launch"]["median"] + k["write_size_bytes_per_launch"]["median"],
-                            "read": k["fetch_size_bytes_per_launch"]["median"],
-                            "written": k["write_size_bytes_per_launch"]["median"],
+                    # mean over the launches of the profiled run's TIMED epochs where the summary has it (same command
+                    # shape as this run: same lanes, seeds, warm-up), else the median over all launches
+                    rd, wr = (x.get("timed_epochs", {}).get("mean", x["median"]) for x in
+                              (k["fetch_size_bytes_per_launch"], k["write_size_bytes_per_launch"]))
+                    return {"bytes": rd + wr, "read": rd, "written": wr,
+                            "restricted_to_timed_epochs": "timed_epochs" in k["fetch_size_bytes_per_launch"],
+                            "profiled_steps_warmup": d.get("steps_warmup"),
                             "source": os.path.relpath(path, ROOT), "kernel": name,
                             "lanes_profiled": d.get("lanes"), "note": d.get("note")}
         return None

@@ -9,7 +9,9 @@ R=$(pwd)
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra-legs ${BENCH_ARGS:-}"
+# the driver's command shape (BENCH_rNN.json: bench.py --gpus 1 --steps 20 --warmup 5), minus the legs that are not the
+# headline (CPU baseline, comparison legs): the timed epochs see the same lanes, seeds and subgame mix as the driver's
+CMD="python3 $R/bench.py --gpus 1 --steps ${STEPS:-20} --warmup ${WARMUP:-5} --no-cpu-baseline --no-extra-legs ${BENCH_ARGS:-}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $CMD > $O/kt.log 2>&1
 grep '^{' $O/kt.log | tail -1 > $O/bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o fetch -- $CMD > $O/fetch.log 2>&1

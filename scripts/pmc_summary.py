@@ -21,7 +21,7 @@ def find(sub, suffix):
 
 
 def short(name):
-    for key in ("mlp_resident_kernel", "mlp_fsplit_forward_kernel", "cfr_rows_kernel", "cfr_wave_kernel", "cfr_big_kernel",
+    for key in ("mlp_resident_kernel", "mlp_pipe_kernel", "mlp_fsplit_forward_kernel", "cfr_rows_kernel", "cfr_wave_kernel", "cfr_big_kernel",
                 "cfr_step_kernel", "sp_begin_kernel", "sp_scan_kernel", "sp_end_kernel", "synthetic_net_kernel"):
         if key in name:
             return name[name.index(key):].split("(")[0]
@@ -31,7 +31,9 @@ def short(name):
 out = {"tag": tag, "kernels": {}, "note": "durations from the --kernel-trace pass (ns); fetch/write from the separate "
        "--pmc passes (kernels serialised by the counter collection), KB -> bytes, FETCH_SIZE x2 (gfx950)"}
 try:
-    out["lanes"] = json.load(open(os.path.join(base, "bench_under_rocprof.json")))["config"]["lanes_per_gpu"]
+    _bj = json.load(open(os.path.join(base, "bench_under_rocprof.json")))
+    out["lanes"] = _bj["config"]["lanes_per_gpu"]
+    out["steps_warmup"] = [_bj["steps"], _bj["warmup"]]
 except Exception:
     out["lanes"] = None
 kt = find("kt", "kernel_trace.csv")
@@ -74,10 +76,20 @@ for sub, cname, scale in (("fetch", "FETCH_SIZE", 2.0), ("write", "WRITE_SIZE", 
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(cc)):
         if r["Counter_Name"] == cname:
-            d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024.0 * scale)
-    for n, v in d.items():
+            d[short(r["Kernel_Name"])].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"]) * 1024.0 * scale))
+    try:
+        bj = json.load(open(os.path.join(base, "bench_under_rocprof.json")))
+        wu, st = int(bj["warmup"]), int(bj["steps"])
+    except Exception:
+        wu, st = 0, 1
+    for n, dv in d.items():
+        dv.sort()
+        v = [x[1] for x in dv]
         # the init / query-only launches of cfr_step_kernel and the first launches (cold caches) are in there too: median
-        out["kernels"].setdefault(n, {})[cname.lower() + "_bytes_per_launch"] = {"mean": sum(v) / len(v),
-                                                                                  "median": statistics.median(v), "n": len(v)}
+        rec = {"mean": sum(v) / len(v), "median": statistics.median(v), "n": len(v)}
+        if len(v) % (wu + st) == 0 and len(v) >= 64:  # a per-iteration kernel: the launches of the bench's TIMED epochs only
+            timed = v[len(v) * wu // (wu + st):]
+            rec["timed_epochs"] = {"mean": sum(timed) / len(timed), "median": statistics.median(timed), "n": len(timed)}
+        out["kernels"].setdefault(n, {})[cname.lower() + "_bytes_per_launch"] = rec
 json.dump(out, open(os.path.join(base, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
