@@ -56,6 +56,9 @@ struct CfrArgs {
   int use_lds;
   // ---- uniform step parameters (lanes are in lock-step)
   int lane0;  // first lane of this launch (half-batches run on separate streams)
+  // cfr_rows_kernel<GS> only: workgroup b serves lane lane_order[lane0 + b] (lanes of a part sorted by tree size, so that a
+  // launch can request the LDS of ITS largest tree and small trees share a CU); null = lane0 + b
+  const int* lane_order;
   int mode, trav, next_trav, steps_after;
   double alpha;            // root-mean step size (subgame_solving.cc:580-590)
   double pos, neg, strat;  // discounts (:592-617); kModeFpStep: strat = linear factor (n+1)/(n+2) or 1

@@ -58,7 +58,10 @@ template <int H, int A, int DICE, int FACES, bool GS>
 __global__ void __launch_bounds__(GS ? 256 : 128) cfr_rows_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
-  const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = (GS && a.lane_order)
+                       ? ((const int __attribute__((address_space(4)))*)a.lane_order)[a.lane0 + blockIdx.x]
+                       : a.lane0 + (int)blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   // The lane's strategy and regrets are requested BEFORE its shape is known (their addresses only depend on the lane; the
   // bound is the slab size, the real extent is applied at the LDS store): the shape look-up (lane -> shape id -> shape
   // record -> tables) is a chain of dependent loads, and the state comes from Infinity Cache / HBM, not from L2.

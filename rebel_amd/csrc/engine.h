@@ -116,6 +116,9 @@ class Engine {
     return EvalView{d_sums_.p,   d_sigma_.p, d_beliefs_.p, d_lane_shape_.p, d_lane_player_.p, d_shapes_.p, d_parent_.p,
                     d_cb_.p,     d_ce_.p,    d_depth_.p,   d_leaves_.p,     {num_steps_[0], num_steps_[1]}, p_.use_cfr != 0};
   }
+  // cfr_rows_kernel<GS> (2 dice x 6 faces) is launched per size-sorted segment of a part: device-resident epochs get the
+  // order from sp_order (selfplay_kernels.hip), which needs this buffer; null when the engine does not sort
+  int* lane_order_dev() const { return use_order_ ? d_lane_order_.p : nullptr; }
   const ShapeDev* shapes_dev() const { return d_shapes_.p; }
   const int* act_dev() const { return d_act_.p; }
   const int* cb_dev() const { return d_cb_.p; }
@@ -210,6 +213,12 @@ class Engine {
   size_t wave_lds_bytes_ = 0;
   bool rows_global_ok_ = false;  // big games: row kernel with sigma / regrets in place in global memory
   size_t rows_global_lds_ = 0;
+  // ... launched per segment of the part's lanes sorted by tree size, each with the LDS request of ITS largest tree: one
+  // root-sized lane per CU (124 KB), but two to four of the smaller trees that make up most of a self-play batch
+  bool use_order_ = false;
+  DevBuf<int> d_lane_order_;
+  size_t seg_lds_[4][kSpSegs] = {};
+  void set_segments(const int (*seg_shape)[kSpSegs]);  // LDS request of each launch segment from its head lane's shape
   size_t part_rows_lds_[4] = {0, 0, 0, 0};  // per part: LDS of the largest tree among its lanes (set by reset)
   int part_rows_block_[4] = {128, 128, 128, 128};
   bool rows_fit_ = true;  // size the row kernel's launch to the largest tree of the part

@@ -186,6 +186,10 @@ void Engine::construct() {
     rows_global_lds_ = std::max(rows_global_lds_, cfr_rows_global_lds_bytes(s.N, s.NI, g_.H, g_.faces));
   rows_global_ok_ = !use_lds_ && env_int("RBL_CFR_ROWS", 1) && cfr_rows_global_supported(g_.H, g_.A, g_.dice, g_.faces) &&
                     rows_global_lds_ <= 160 * 1024;
+  use_order_ = rows_global_ok_ && env_int("RBL_GS_SORT", 1) != 0;
+  if (use_order_) d_lane_order_.alloc((size_t)max_lanes_);
+  for (auto& row : seg_lds_)
+    for (size_t& v : row) v = rows_global_lds_;
   rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   cfr_dbg_ = env_int("RBL_CFR_DBG", 0) != 0;
@@ -444,6 +448,23 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
   part_lanes(B, part_lane_);
+  if (use_order_) {  // lanes of each part by tree size, largest first (= shape id ascending), ties by lane index
+    std::vector<int> order(B);
+    int seg_shape[4][kSpSegs] = {};
+    for (int pt = 0; pt < n_parts_; ++pt) {
+      const int l0 = part_lane_[pt], l1 = part_lane_[pt + 1];
+      for (int i = l0; i < l1; ++i) order[i] = i;
+      std::stable_sort(order.begin() + l0, order.begin() + l1, [&](int x, int y) { return h_shape_[x] < h_shape_[y]; });
+      const int ns = sp_segments(l1 - l0);
+      for (int k = 0; k < ns && l1 > l0; ++k) {
+        const int first = l0 + (int)((long long)(l1 - l0) * k / ns);
+        seg_shape[pt][k] = h_shape_[order[std::min(first, l1 - 1)]];
+      }
+    }
+    d_lane_order_.upload(order, stream_);
+    RBL_HIP_CHECK(hipStreamSynchronize(stream_));  // `order` goes out of scope
+    set_segments(seg_shape);
+  }
   for (int pt = 0; pt <= n_parts_; ++pt) part_row_[pt] = pt == n_parts_ ? rows : h_row_[part_lane_[pt]];
   for (int pt = 0; pt < 4; ++pt) {
     part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
@@ -515,10 +536,26 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
     part_rows_block_[pt] = rows_block_;
   }
   for (int pt = 0; pt <= n_parts_; ++pt) part_row_[pt] = (int64_t)part_lane_[pt] * tabs_.max_L;  // bounds only
+  if (use_order_) {  // the one thing the host does learn before the epoch: the head shape of each launch segment (sp_order)
+    int seg_shape[kSpMaxParts][kSpSegs];
+    RBL_HIP_CHECK(hipMemcpyAsync(seg_shape, info_dev->seg_shape, sizeof(seg_shape), hipMemcpyDeviceToHost, stream_));
+    RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+    set_segments(seg_shape);
+  }
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
   for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
+}
+
+void Engine::set_segments(const int (*seg_shape)[kSpSegs]) {
+  for (int pt = 0; pt < 4; ++pt)
+    for (int k = 0; k < kSpSegs; ++k) {
+      const int sid = pt < n_parts_ ? seg_shape[pt][k] : 0;
+      if (sid < 0 || sid >= (int)tabs_.shapes.size()) throw std::runtime_error("engine: bad segment head shape");
+      const ShapeDev& sh = tabs_.shapes[sid];
+      seg_lds_[pt][k] = cfr_rows_global_lds_bytes(sh.N, sh.NI, g_.H, g_.faces);
+    }
 }
 
 void Engine::join_streams() {
@@ -636,6 +673,19 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     int which = 0;
     if (mode == kModeStep && wave_ok_ && launch_cfr_wave(a, cnt, wave_lds_bytes_, st)) {
       which = 2;
+    } else if (mode == kModeStep && rows_global_ok_ && use_order_) {
+      // one launch per size-sorted segment of the part, each with the LDS request of its largest tree
+      a.lane_order = d_lane_order_.p;
+      const int ns = sp_segments(cnt);
+      for (int k = 0; k < ns; ++k) {
+        const int p0 = l0 + (int)((long long)cnt * k / ns), p1 = l0 + (int)((long long)cnt * (k + 1) / ns);
+        if (p1 <= p0) continue;
+        a.lane0 = p0;
+        launch_cfr_rows_global(a, p1 - p0, seg_lds_[part][k], st);
+      }
+      a.lane_order = nullptr;
+      a.lane0 = l0;
+      which = 3;
     } else if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
       which = 3;
     } else if (mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)) {
@@ -1373,6 +1423,7 @@ SpArgs SelfPlay::sp_args() const {
   a.ex_q = d_ex_q_.p;
   a.ex_v = d_ex_v_.p;
   a.info = d_info_.p;
+  a.lane_order = e_->lane_order_dev();
   a.n_parts = e_->parts_for(n_);
   e_->part_lanes(n_, a.part_lane);
   return a;
@@ -1390,6 +1441,7 @@ int64_t SelfPlay::advance_device(rbl_example_fn sink, void* user) {
   const SpArgs a = sp_args();
   launch_sp_begin(a, st);
   launch_sp_scan(a, st);
+  if (a.lane_order) launch_sp_order(a, st);
   RBL_HIP_CHECK(hipGetLastError());
   e_->begin_epoch_device(n_, d_info_.p);
   e_->multistep(num_iters);

@@ -13,6 +13,13 @@
 namespace rbl {
 
 constexpr int kSpMaxParts = 4;
+constexpr int kSpSegs = 8;  // most launches per part of the size-sorted CFR kernel (cfr_rows_kernel<GS>, 2 dice x 6 faces)
+// launches of a part with `lanes` lanes: each must still fill the GPU (256 CUs, one to four lanes per CU), or the small launches
+// of a stream run one after the other on a half-empty chip
+__host__ __device__ inline int sp_segments(int lanes) {
+  const int s = lanes / 512;
+  return s < 1 ? 1 : (s > kSpSegs ? kSpSegs : s);
+}
 
 // Written by sp_scan at the start of an epoch, read back (pinned, async) with the examples at its end.
 struct SpEpochInfo {
@@ -20,6 +27,7 @@ struct SpEpochInfo {
   unsigned long long part_bytes[kSpMaxParts][2];    // algorithmic bytes of one CFR step per part and traverser
   unsigned long long games;                         // games finished so far (all epochs)
   long long rows;                                   // = part_row[n_parts]
+  int seg_shape[kSpMaxParts][kSpSegs];              // shape of the largest tree of each launch segment (sp_order)
 };
 
 struct SpArgs {
@@ -52,6 +60,7 @@ struct SpArgs {
   float* ex_q;  // [2n][Q]
   float* ex_v;  // [2n][H]
   SpEpochInfo* info;
+  int* lane_order;  // [n] lanes of each part sorted by tree size, largest first (null: not wanted)
   int n_parts;
   int part_lane[kSpMaxParts + 1];
 };
@@ -61,6 +70,7 @@ void mt19937_seed_state(uint32_t seed, uint32_t* state624);
 
 void launch_sp_begin(const SpArgs& a, hipStream_t st);  // reset finished games, draw act_iteration, descriptors
 void launch_sp_scan(const SpArgs& a, hipStream_t st);   // lane_row prefix sums, part boundaries, byte accounting
+void launch_sp_order(const SpArgs& a, hipStream_t st);  // lanes of each part sorted by tree size; segment heads -> info
 void launch_sp_end(const SpArgs& a, hipStream_t st);    // sampling walk, Bayes updates, examples
 
 // test hook: n_draws of each kind from one lane's generator, in this order per round: uniform_int(0, hi), canonical

@@ -187,6 +187,43 @@ __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
   if (t < kSpMaxParts * 2) a.info->part_bytes[t >> 1][t & 1] = bytes[t >> 1][t & 1];
 }
 
+// Lanes of each part in order of tree size, largest first, ties by lane index: a stable counting sort by shape id (a
+// subgame's tree shrinks as its root's last bid grows, so the shape id IS the size rank).  One thread per shape; the lane
+// count of a 2 dice x 6 faces engine is a few thousand, and this runs once per epoch.  Then the shape at the head of each
+// of the kSpSegs equal launch segments of a part: the host sizes each launch's LDS request by it.
+__global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
+  __shared__ int start[kSpMaxParts][128];
+  const int s = threadIdx.x, n_shapes = a.A;  // shapes 0 .. A-1 (root_last_bid + 1)
+  for (int p = 0; p < a.n_parts; ++p) {
+    const int l0 = a.part_lane[p], l1 = a.part_lane[p + 1];
+    int cnt = 0;
+    if (s < n_shapes)
+      for (int i = l0; i < l1; ++i) cnt += a.lane_shape[i] == s;
+    start[p][s] = cnt;
+    __syncthreads();
+    if (s == 0) {
+      int run = l0;
+      for (int k = 0; k < n_shapes; ++k) {
+        const int c = start[p][k];
+        start[p][k] = run;
+        run += c;
+      }
+    }
+    __syncthreads();
+    if (s < n_shapes) {
+      int w = start[p][s];
+      for (int i = l0; i < l1; ++i)
+        if (a.lane_shape[i] == s) a.lane_order[w++] = i;
+    }
+    __syncthreads();
+    if (s < kSpSegs) {
+      const int cnt_p = l1 - l0, ns = sp_segments(cnt_p), first = l0 + (int)((long long)cnt_p * (s < ns ? s : 0) / ns);
+      a.info->seg_shape[p][s] = cnt_p > 0 ? a.lane_shape[a.lane_order[first < l1 ? first : l1 - 1]] : 0;
+    }
+    __syncthreads();
+  }
+}
+
 // write_query_to (subgame_solving.cc:104-123) for the subgame root
 __device__ void write_root_query(const SpArgs& a, int traverser, int last_bid, int player, const double* b0,
                                  const double* b1, float* q) {
@@ -310,6 +347,11 @@ void mt19937_seed_state(uint32_t seed, uint32_t* x) {
 void launch_sp_begin(const SpArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(sp_begin_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 }
+void launch_sp_order(const SpArgs& a, hipStream_t st) {
+  if (a.A > 128) return;
+  hipLaunchKernelGGL(sp_order_kernel, dim3(1), dim3(128), 0, st, a);
+}
+
 void launch_sp_scan(const SpArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(1024), 0, st, a);
 }
