@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(extra, env=None):
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--lanes", "1536", "--iters", "48",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--lanes", "2560", "--iters", "48",
            "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -28,12 +28,14 @@ def test_bench_json_contract_small():
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_cfr"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["lanes_per_gpu"] == 1536 and d["selfplay_walk"] == "device kernels"
+    assert d["config"]["lanes_per_gpu"] == 2560 and d["selfplay_walk"] == "device kernels"
+    assert d["streams"] == 2  # what the engine ran (two lane parts from 2 048 lanes on), reported by rbl_engine_stats
+    assert "cfr_wave_kernel" in d["roofline_cfr"]["kernel"] and "mlp_resident_kernel" in d["roofline"]["kernel"]
     for key in ("roofline", "roofline_cfr"):
         r = d[key]
         assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
         assert r["standalone"]["achieved"] > 0  # the stand-alone leg ran
-    assert abs(d["value"] - 2 * 1536 * 48 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert abs(d["value"] - 2 * 2560 * 48 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
 def test_bench_force_dist_single_rank_rccl():
