@@ -29,7 +29,7 @@ namespace rbl {
 namespace {
 
 constexpr double kEps = 1e-80;
-constexpr size_t kWaveLdsSlack = 256;  // bytes behind the lane's LDS image that the unconditional staging stores may touch
+constexpr size_t kWaveLdsSlack = 128;  // bytes behind the lane's LDS image that the unconditional staging stores may touch
 
 template <int H>
 struct Row {
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
   constexpr int KS = (EHM + W - 1) / W;
-  constexpr int KT = ((7 * NM + LHM / H + 3) / 4 + W - 1) / W;  // dword strides of the byte-table blob (6 N + L + T bytes)
+  constexpr int KT = ((5 * NM + 3) / 4 + W - 1) / W;  // dword strides of the byte-table blob (4 N + L + T <= 5 N bytes)
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x;
   typedef const int __attribute__((address_space(4)))* cint_p;
   typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
@@ -96,14 +96,23 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   // ---- LDS layout
   double* sig = lds;                 // [E][H]
   double* val = sig + EH;            // [N][H]
-  double* rho0 = val + N * H;        // [NI][H]
-  double* rho1 = rho0 + NI * H;
+  // Reach rows are kept for the nodes that have children.  In a tree of depth <= 2 (all this kernel takes) only the ROOT's
+  // mover has a reach that differs between those rows; the other player's reach is the same at the root and at every depth-1
+  // node (it moves at depth 1, i.e. into nodes that keep no row): one row instead of NI.
+  double* rho_rp = val + N * H;      // [NI][H] reach of the root's mover
+  double* rho_op = rho_rp + NI * H;  // [1][H]  reach of the other player
+  auto rrow = [&](int pl, int ir) -> double* { return pl == root_player ? rho_rp + ir * H : rho_op; };
+  // nodes with children are a prefix of the BFS order here (the host checks it), and a node's depth follows from the level
+  // offsets: no irank / depth tables
+  const int lo1 = shc->lev_off[1], lo2 = shc->lev_off[2];
+  auto irank = [&](int n) { return n < NI ? n : -1; };
+  auto dpar = [&](int n) { return ((n >= lo1) + (n >= lo2)) & 1; };
   // (the regret-matching row sums live in the value rows of the level they normalise, which are dead by then; their
   // refined reciprocals are recomputed where they are used: 10.6 KB per root lane instead of 12.1 KB = 15 lanes per CU)
   // tree tables as bytes: every entry is a node id, an action, a row index or -1, all < 128 for these games (NM <= 127)
-  int8_t* tb = reinterpret_cast<int8_t*>(rho1 + NI * H);
-  int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
-  int8_t *t_irank = tb + 5 * N, *t_leaf = tb + 6 * N, *t_term = t_leaf + L;  // t_leaf[k]: node of net row k; t_term[j]: j-th terminal
+  int8_t* tb = reinterpret_cast<int8_t*>(rho_op + H);
+  int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N;
+  int8_t *t_leaf = tb + 4 * N, *t_term = t_leaf + L;  // t_leaf[k]: node of net row k; t_term[j]: j-th terminal
   int8_t* t_match = t_term + T;
 
   long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
@@ -160,8 +169,8 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     else
       load_sig(std::integral_constant<int, KS>{});
     // (the net's output rows go straight into the registers of the thread that will consume them: lv_ below)
-    // the lane's tree tables: one byte blob per shape in exactly the LDS layout (parent, act, cb, ce, depth, irank: N bytes
-    // each; leaf nodes: L; terminal nodes: T), copied dword-wise (was: eight int tables, 16 loads per thread, 4 bytes per entry)
+    // the lane's tree tables: one byte blob per shape in exactly the LDS layout (parent, act, cb, ce: N bytes each; leaf
+    // nodes: L; terminal nodes: T), copied dword-wise (was: eight int tables, 16 loads per thread, 4 bytes per entry)
     const int* gt = reinterpret_cast<const int*>(a.wave_tabs + ((cint_p)a.wave_tab_off)[((cint_p)a.lane_shape)[lane]]) + tid;
     int tw[KT];
 #pragma unroll
@@ -184,8 +193,8 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     else
       store_sig(std::integral_constant<int, KS>{});
     if (tid < H) {
-      rho0[tid] = b0;
-      rho1[tid] = b1;
+      rrow(0, 0)[tid] = b0;
+      rrow(1, 0)[tid] = b1;
     }
 #pragma unroll
     for (int u = 0; u < KT; ++u) reinterpret_cast<int*>(tb)[tid + u * W] = tw[u];
@@ -204,29 +213,21 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   // opponent-reach row at once (scale sum / match histogram): those two passes are row-per-thread.
   auto opp_reach_row = [&](int n) {  // opponent's reach at childless node n: the parent's row, times sigma if the opponent acted
     const int p = t_parent[n];
-    Row<H> ro = load_row<H>((opp == 0 ? rho0 : rho1) + t_irank[p] * H);
-    if ((root_player ^ (t_depth[p] & 1)) == opp) {
+    Row<H> ro = load_row<H>(rrow(opp, irank(p)));
+    if ((root_player ^ dpar(p)) == opp) {
       const Row<H> sg = load_row<H>(sig + (n - 1) * H);
 #pragma unroll
       for (int h = 0; h < H; ++h) ro.v[h] = ro.v[h] * sg.v[h];
     }
     return ro;
   };
-  for (int lev = 1; lev < nlev - 1; ++lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
-    const int mover = root_player ^ ((lev - 1) & 1);
-    double* rho_m = mover == 0 ? rho0 : rho1;
-    double* rho_n = mover == 0 ? rho1 : rho0;
-    for (int n = n0 + tid; n < n1; n += W) {
-      const int ir = t_irank[n];
-      if (ir < 0) continue;
-      const int pr = t_irank[t_parent[n]];
-      Row<H> rm = load_row<H>(rho_m + pr * H);
-      const Row<H> rn = load_row<H>(rho_n + pr * H), sg = load_row<H>(sig + (n - 1) * H);
+  if (nlev > 2) {  // depth-1 nodes with children: the root's mover acted on the way in (the other player's row is the root's)
+    for (int n = lo1 + tid; n < NI; n += W) {
+      Row<H> rm = load_row<H>(rho_rp);
+      const Row<H> sg = load_row<H>(sig + (n - 1) * H);
 #pragma unroll
       for (int h = 0; h < H; ++h) rm.v[h] = rm.v[h] * sg.v[h];
-      store_row<H>(rho_m + ir * H, rm);
-      store_row<H>(rho_n + ir * H, rn);
+      store_row<H>(rho_rp + n * H, rm);
     }
     wave_sync();
   }
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     const int k = tid + u * W;
     if (k < L) {
       const int n = t_leaf[k];
-      const Row<H> ro = n == 0 ? load_row<H>(opp == 0 ? rho0 : rho1) : opp_reach_row(n);
+      const Row<H> ro = n == 0 ? load_row<H>(rrow(opp, 0)) : opp_reach_row(n);
       double ssum = 0.0;
 #pragma unroll
       for (int h = 0; h < H; ++h) ssum += ro.v[h];
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   }
   for (int j = tid; j < T; j += W) {  // terminals: the bid that was called is the parent's last bid (:80-98, :765-789)
     const int n = t_term[j];
-    const Row<H> ro = n == 0 ? load_row<H>(opp == 0 ? rho0 : rho1) : opp_reach_row(n);
+    const Row<H> ro = n == 0 ? load_row<H>(rrow(opp, 0)) : opp_reach_row(n);
     const int bid = n == 0 ? 0 : t_act[t_parent[n]];
     const int qty = 1 + bid / FACES, face = bid % FACES;
     const int8_t* m = t_match + face * H;
@@ -264,7 +265,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     }
 #pragma unroll
     for (int k = DICE - 1; k >= 0; --k) b[k] += b[k + 1];  // bins above DICE are +0.0: adding them changes no bit
-    const bool inverse = (root_player ^ (t_depth[n] & 1)) != t;
+    const bool inverse = (root_player ^ dpar(n)) != t;
     double cand[DICE + 1];
 #pragma unroll
     for (int mm = 0; mm <= DICE; ++mm) {
@@ -293,7 +294,9 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 
   // ---------------------------------------------------------------- bottom-up (update_regrets :542-574) fused with regret
   // matching (:619-634) and the regret discount (:639-650); element-parallel
-  double* rho_t = t == 0 ? rho0 : rho1;
+  // the traverser's reach rows: the full set if it moves at the root, else the single row (index multiplier 0)
+  double* rho_t = t == root_player ? rho_rp : rho_op;
+  const int tmul = t == root_player ? 1 : 0;
   // Per-thread view of a traverser level's edge elements i = tid + 64 u (element = (child c, hand h) of the level below):
   // its regret and strategy-sum values (requested from global memory up front), the LDS offsets of its parent's value /
   // reach row.  The regret update, the normalisation and the strategy-sum update all walk this same element set, so the
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         gs_[u] = g_sum[(c_lo - 1) * H + i];
         const int p = t_parent[c_lo + i / H], h = i % H;
         pv[u] = p * H + h;
-        pr[u] = t_irank[p] * H + h;
+        pr[u] = irank(p) * H + h;
       }
     }
     for (int i = tid; i < nh; i += W) {  // node value of (n, h): sequential over the actions, ascending
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     // the children's values have been consumed (regret update above): their rows now hold the row sums, one row per node
     // of this level that has children (those nodes' reach-row ranks are consecutive; every one of them has >= 1 child)
     double* ysum = val + c_lo * H;
-    const int irk0 = t_irank[n0];
+    const int irk0 = irank(n0);
     for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         if (c + 2 < c1) s += s2;
         if (c + 3 < c1) s += s3;
       }
-      ysum[(t_irank[n] - irk0) * H + h] = s;
+      ysum[(irank(n) - irk0) * H + h] = s;
     }
     wave_sync();
 #pragma unroll
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       }
     }
     for (int i = tid + KS * W; i < ch; i += W) {
-      const int ir = t_irank[t_parent[c_lo + i / H]], h = i % H;
+      const int ir = irank(t_parent[c_lo + i / H]), h = i % H;
       const double s = ysum[(ir - irk0) * H + h];
       lsig[i] = div_by(lsig[i], s, refine_rcp(s));
     }
@@ -418,17 +421,11 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   }
   // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638), rows of
   // nodes with children only (the root row still holds the traverser's beliefs)
-  for (int lev = 1; lev < nlev - 1; ++lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
-    const bool own = (root_player ^ ((lev - 1) & 1)) == t;
-    const int nh = (n1 - n0) * H;
+  if (nlev > 2 && tmul) {  // depth-1 rows of the root's mover, if it is the traverser (the other player's single row stands)
+    const int nh = (NI - lo1) * H;
     for (int i = tid; i < nh; i += W) {
-      const int n = n0 + i / H, h = i % H;
-      const int ir = t_irank[n];
-      if (ir < 0) continue;
-      double r = rho_t[t_irank[t_parent[n]] * H + h];
-      if (own) r = r * sig[(n - 1) * H + h];
-      rho_t[ir * H + h] = r;
+      const int n = lo1 + i / H, h = i % H;
+      rho_rp[n * H + h] = rho_rp[h] * sig[(n - 1) * H + h];
     }
     wave_sync();
   }
@@ -448,18 +445,18 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
           const double sg = sig[e0 + i];
           double x = gs_[u];
           x *= a.strat;
-          x += rho_t[pr[u]] * sg;
+          x += rho_t[tmul ? pr[u] : (tid + u * W) % H] * sg;
           g_sum[e0 + i] = x;
           g_sig[e0 + i] = sg;
         }
       }
     }
     for (int i = tid + (lev == lev_kept ? KS * W : 0); i < ch; i += W) {
-      const int ir = t_irank[t_parent[c_lo + i / H]], h = i % H;
+      const int ir = irank(t_parent[c_lo + i / H]), h = i % H;
       const double sg = sig[e0 + i];
       double x = g_sum[e0 + i];
       x *= a.strat;
-      x += rho_t[ir * H + h] * sg;
+      x += rho_t[ir * tmul * H + h] * sg;
       g_sum[e0 + i] = x;
       g_sig[e0 + i] = sg;
     }
@@ -482,15 +479,14 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     const float trav_flag = (float)a.next_trav;
     for (int j = tid; j < 2 * L; j += W) {
       const int k = j >> 1, pl = j & 1, n = t_leaf[k];
-      const double* rbase = pl == 0 ? rho0 : rho1;
       Row<H> r;
-      const int ir = t_irank[n];
+      const int ir = irank(n);
       if (ir >= 0) {  // only the root can be a pseudo-leaf with a stored row (max_depth = 0)
-        r = load_row<H>(rbase + ir * H);
+        r = load_row<H>(rrow(pl, ir));
       } else {
         const int p = t_parent[n];
-        r = load_row<H>(rbase + t_irank[p] * H);
-        if ((root_player ^ (t_depth[p] & 1)) == pl) {
+        r = load_row<H>(rrow(pl, irank(p)));
+        if ((root_player ^ dpar(p)) == pl) {
           const Row<H> sg = load_row<H>(sig + (n - 1) * H);
 #pragma unroll
           for (int h = 0; h < H; ++h) r.v[h] = r.v[h] * sg.v[h];
@@ -513,8 +509,8 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 }  // namespace
 
 size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
-  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)2 * NI * H;  // doubles
-  const size_t b = d * 8 + (size_t)(6 * N + L + T) + (size_t)faces * H;
+  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)(NI + 1) * H;  // doubles: sigma, values, reach rows
+  const size_t b = d * 8 + (size_t)(4 * N + L + T) + (size_t)faces * H;
   return ((b + 15) & ~(size_t)15) + kWaveLdsSlack;
 }
 

@@ -111,7 +111,7 @@ void Engine::construct() {
     for (const ShapeDev& s : tabs_.shapes) {
       while (blob.size() % 4) blob.push_back(0);
       off.push_back((int)blob.size());
-      for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce, &tabs_.depth, &tabs_.irank})
+      for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce})
         for (int n = 0; n < s.N; ++n) blob.push_back((int8_t)(*tab)[s.node_off + n]);
       for (int k = 0; k < s.L; ++k) blob.push_back((int8_t)tabs_.leaves[s.leaf_off + k]);
       for (int k = 0; k < s.T; ++k) blob.push_back((int8_t)tabs_.terms[s.term_off + k]);
@@ -177,7 +177,14 @@ void Engine::construct() {
       max_lh = std::max(max_lh, s.L * g_.H);
       wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces));
     }
-    wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 &&
+    // the kernel's tree model: depth <= 2 and the nodes with children first in BFS order (reach-row rank = node id)
+    bool prefix_ok = true;
+    for (const ShapeDev& s : tabs_.shapes) {
+      if (s.nlev > 3) prefix_ok = false;
+      for (int n = 0; n < s.N; ++n)
+        if (tabs_.irank[s.node_off + n] != (n < s.NI ? n : -1)) prefix_ok = false;
+    }
+    wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 && prefix_ok &&
                cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
   }
   // big games (2 dice x 6 faces): the row kernel with the strategy arrays in place in global memory
