@@ -99,6 +99,31 @@ def test_selfplay_2d6f_global_scratch_path(port):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
 
 
+def test_selfplay_2d6f_size_sorted_launches_change_nothing(monkeypatch, port):
+    """2 dice x 6 faces runs its CFR kernel per size-sorted SEGMENT of a lane part (device counting sort per epoch, one LDS
+    request per segment; >= 1024 lanes per part = two or more segments): the example streams equal those of the unsorted
+    launch order (RBL_GS_SORT=0) bit for bit, and sampled lanes equal the oracle's."""
+    from oracle import orc
+
+    c = dict(d=2, f=6, p=dict(num_iters=6, max_depth=2, linear_update=True, use_cfr=True), rap=0.25, leaf=True,
+             net="synthetic")
+    seeds = list(range(2000, 2000 + 2304))  # two parts of 1 152 lanes = two segments each
+    sorted_runs = _run_lanes(c, seeds, 1)
+    monkeypatch.setenv("RBL_GS_SORT", "0")
+    plain = _run_lanes(c, seeds, 1)
+    monkeypatch.delenv("RBL_GS_SORT")
+    for a, b in zip(sorted_runs, plain):
+        assert len(a) == len(b)
+        for (q, v), (rq, rv) in zip(a, b):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv)
+    for i in (0, 700, 1151, 1152, 2303):
+        ref = port.rl_run(c["d"], c["f"], orc.make_params(**c["p"]), seeds[i], 1, random_action_prob=c["rap"],
+                          sample_leaf=c["leaf"], net=orc.NET_SYNTHETIC)
+        assert len(sorted_runs[i]) == len(ref), i
+        for (q, v), (rq, rv) in zip(sorted_runs[i], ref):
+            assert np.array_equal(q, rq) and np.array_equal(v, rv), i
+
+
 def test_selfplay_fictitious_play_lanes(port):
     """use_cfr=false is the pybind default (subgame_solving.h:48): self-play with the FP solver (optimistic, linear)
     reproduces the oracle per seed as well."""
