@@ -50,6 +50,11 @@ struct CfrArgs {
   // ---- net exchange
   float* queries;       // [rows][Q]
   const float* values;  // [rows][H]
+  // split query layout (cfr_wave_kernel + the fused MLP forward): what changes between iterations -- traverser flag, the two
+  // normalised reach vectors -- as contiguous rows [rows][q_dyn_stride] (stride a multiple of 4 floats, pads written as 0), so
+  // that a step writes whole lines instead of 52-byte runs inside 108-byte rows; null = write `queries`
+  float* q_dyn;
+  int q_dyn_stride;
   // ---- global scratch for lanes too big for LDS: [B][work_reals]
   double* scratch;
   size_t work_stride;
@@ -81,6 +86,13 @@ void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out,
                           const long long* range = nullptr);
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
+
+// canonical query rows [rows][Q] = (player, traverser, one-hot last bid [A], reach0 [H], reach1 [H]) <-> split layout:
+// dyn [rows][DS] = (traverser, reach0, reach1, 0...), stat [rows][SS] = (player, one-hot, 0...); `range` as in the net launch
+void launch_split_queries(const float* canon, int A, int H, float* dyn, int DS, float* stat, int SS, int64_t rows,
+                          hipStream_t stream, const long long* range = nullptr);
+void launch_unsplit_queries(float* canon, int A, int H, const float* dyn, int DS, const float* stat, int SS, int64_t rows,
+                            hipStream_t stream);
 
 // cfr_rows_kernel.hip: kModeStep with one thread per tree row, for LDS-resident lanes of the common games.
 // Returns false (nothing launched) when the game has no instantiation.

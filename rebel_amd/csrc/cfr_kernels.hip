@@ -495,6 +495,54 @@ __global__ void synthetic_net_kernel(const float* __restrict__ queries, int64_t 
 
 }  // namespace
 
+__global__ void split_queries_kernel(const float* __restrict__ canon, int A, int H, float* __restrict__ dyn, int DS,
+                                     float* __restrict__ stat, int SS, int64_t rows, const long long* __restrict__ range) {
+  const int Q = 2 + A + 2 * H, W = DS + SS;
+  if (range) {
+    canon += range[0] * Q;
+    dyn += range[0] * DS;
+    stat += range[0] * SS;
+    rows = range[1] - range[0];
+  }
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = i / W;
+  if (r >= rows) return;
+  const int j = (int)(i % W);
+  const float* c = canon + r * Q;
+  if (j < DS)
+    dyn[r * DS + j] = j == 0 ? c[1] : (j <= 2 * H ? c[2 + A + j - 1] : 0.f);
+  else {
+    const int s = j - DS;
+    stat[r * SS + s] = s == 0 ? c[0] : (s <= A ? c[2 + s - 1] : 0.f);
+  }
+}
+
+__global__ void unsplit_queries_kernel(float* __restrict__ canon, int A, int H, const float* __restrict__ dyn, int DS,
+                                       const float* __restrict__ stat, int SS, int64_t rows) {
+  const int Q = 2 + A + 2 * H;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = i / Q;
+  if (r >= rows) return;
+  const int k = (int)(i % Q);
+  canon[i] = k == 0 ? stat[r * SS] : (k == 1 ? dyn[r * DS] : (k < 2 + A ? stat[r * SS + 1 + k - 2] : dyn[r * DS + 1 + k - 2 - A]));
+}
+
+void launch_split_queries(const float* canon, int A, int H, float* dyn, int DS, float* stat, int SS, int64_t rows,
+                          hipStream_t stream, const long long* range) {
+  if (rows <= 0) return;
+  const int64_t n = rows * (DS + SS);
+  hipLaunchKernelGGL(split_queries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, canon, A, H, dyn, DS,
+                     stat, SS, rows, range);
+}
+
+void launch_unsplit_queries(float* canon, int A, int H, const float* dyn, int DS, const float* stat, int SS, int64_t rows,
+                            hipStream_t stream) {
+  if (rows <= 0) return;
+  const int64_t n = rows * (2 + A + 2 * H);
+  hipLaunchKernelGGL(unsplit_queries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, canon, A, H, dyn, DS,
+                     stat, SS, rows);
+}
+
 void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out, int H, int A, hipStream_t stream,
                           const long long* range) {
   if (rows <= 0) return;

@@ -496,6 +496,15 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 #pragma unroll
       for (int h = 0; h < H; ++h) ssum += r.v[h] + kEps;
       const double y = refine_rcp(ssum);
+      if (a.q_dyn) {  // split layout: (traverser, reach0, reach1, pads) as one contiguous row per pseudo-leaf
+        float* qd = a.q_dyn + ((size_t)row_off + k) * a.q_dyn_stride;
+#pragma unroll
+        for (int h = 0; h < H; ++h) qd[1 + pl * H + h] = (float)div_by(r.v[h] + kEps, ssum, y);
+        if (pl == 0) qd[0] = trav_flag;
+        else
+          for (int z = 1 + 2 * H; z < a.q_dyn_stride; ++z) qd[z] = 0.f;
+        continue;
+      }
       float* q = gq + k * Q + 2 + A + pl * H;
 #pragma unroll
       for (int h = 0; h < H; ++h) q[h] = (float)div_by(r.v[h] + kEps, ssum, y);

@@ -200,6 +200,12 @@ class Engine {
   NetMode net_mode_ = NetMode::kZero;
   bool values_zeroed_ = false;
   MlpDev mlp_;
+  // split query layout between cfr_wave_kernel and the resident MLP forward (cfr_kernels.h: CfrArgs::q_dyn): on when both are
+  // in use; the canonical [rows][Q] buffer is then current only after the init / query-only launches (get_queries rebuilds it)
+  bool qsplit_ = false, q_canon_stale_ = false;
+  int q_ds_ = 0, q_ss_ = 0, mlp_n_in_true_ = 0;
+  DevBuf<float> d_qdyn_, d_qstat_, d_tmp_dyn_, d_tmp_stat_;
+  void split_part_queries(int part, hipStream_t st);  // canonical rows of a lane part -> dyn / stat rows
   rbl_net_fn cb_fn_ = nullptr;
   void* cb_user_ = nullptr;
   bool cb_host_ = true;

@@ -244,6 +244,7 @@ void Engine::check_lane(int lane) const {
 // ---------------------------------------------------------------------------------------------- value net
 void Engine::set_net_zero() {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
+  qsplit_ = false;
   RBL_HIP_CHECK(hipSetDevice(device_));
   net_mode_ = NetMode::kZero;
   RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
@@ -252,6 +253,7 @@ void Engine::set_net_zero() {
 
 void Engine::set_net_synthetic() {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
+  qsplit_ = false;
   net_mode_ = NetMode::kSynthetic;
   values_zeroed_ = false;
 }
@@ -259,6 +261,7 @@ void Engine::set_net_synthetic() {
 void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (!fn) throw std::runtime_error("set_net_callback: null function");
+  qsplit_ = false;
   net_mode_ = NetMode::kCallback;
   cb_fn_ = fn;
   cb_user_ = user;
@@ -276,7 +279,28 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
     throw std::runtime_error("set_net_mlp: net output size " + std::to_string(w.n_out) + " != num_hands " +
                              std::to_string(g_.H));
   const int tile = env_int("RBL_MLP_TILE", 5);  // 5 = persistent register-resident kernel, 3 = feature-split fallback
-  MlpPacked pk = pack_mlp(w.n_layers, w.n_in, w.n_hidden, w.n_out, w.use_layer_norm, w.w, w.b, w.ln_w, w.ln_b,
+  // Split query layout (cfr_kernels.h): the one-wavefront CFR kernel writes only what changes per iteration, as contiguous
+  // rows; the resident forward reads (dynamic row | static row) as its input, layer 0 packed for that column order.
+  const int ds = (1 + 2 * g_.H + 3) & ~3, ss = (1 + g_.A + 3) & ~3;
+  const bool split = wave_ok_ && p_.use_cfr && tile == 5 && env_int("RBL_QSPLIT", 1) != 0 &&
+                     mlp_resident_supported(w.n_layers, ds + ss, w.n_hidden, w.n_out);
+  std::vector<float> w0v;
+  std::vector<const float*> wv(w.w, w.w + w.n_layers);
+  int n_in_pack = w.n_in;
+  if (split) {
+    n_in_pack = ds + ss;
+    w0v.assign((size_t)w.n_hidden * n_in_pack, 0.f);
+    for (int f = 0; f < w.n_hidden; ++f) {
+      const float* src = w.w[0] + (size_t)f * w.n_in;
+      float* dst = w0v.data() + (size_t)f * n_in_pack;
+      dst[0] = src[1];                                                         // traverser flag
+      for (int j = 0; j < 2 * g_.H; ++j) dst[1 + j] = src[2 + g_.A + j];       // the two reach vectors
+      dst[ds] = src[0];                                                        // player to move
+      for (int a2 = 0; a2 < g_.A; ++a2) dst[ds + 1 + a2] = src[2 + a2];        // one-hot last bid
+    }
+    wv[0] = w0v.data();
+  }
+  MlpPacked pk = pack_mlp(w.n_layers, n_in_pack, w.n_hidden, w.n_out, w.use_layer_norm, wv.data(), w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be
   // enqueued while we hold net_mutex_, and the ones already enqueued on either stream are drained first
@@ -285,7 +309,20 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   mlp_ = MlpDev{};
   mlp_.n_layers = w.n_layers;
-  mlp_.n_in = w.n_in;
+  mlp_.n_in = n_in_pack;
+  mlp_n_in_true_ = w.n_in;
+  qsplit_ = split && pk.tile == 5;
+  q_ds_ = ds;
+  q_ss_ = ss;
+  if (qsplit_) {
+    const size_t max_rows = std::max<size_t>(1, (size_t)max_lanes_ * tabs_.max_L);
+    if (d_qdyn_.n < max_rows * ds) d_qdyn_.alloc(max_rows * ds);
+    if (d_qstat_.n < max_rows * ss) d_qstat_.alloc(max_rows * ss);
+    mlp_.q_stat = d_qstat_.p;
+    mlp_.q_dyn_stride = ds;
+    mlp_.q_stat_stride = ss;
+  }
+  q_canon_stale_ = false;
   mlp_.n_hidden = w.n_hidden;
   mlp_.n_out = w.n_out;
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
@@ -328,7 +365,17 @@ void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, h
       launch_synthetic_net(q_dev, rows, Q, out_dev, H, g_.A, st, range);
       break;
     case NetMode::kMlp:
-      launch_mlp_forward(mlp_, q_dev, rows, out_dev, st, range);
+      if (qsplit_) {  // canonical rows from a caller (rbl_net_forward): through temporaries in the layout the packed net reads
+        if (range) throw std::runtime_error("net: canonical queries with a device-side range are not used in split mode");
+        if (d_tmp_dyn_.n < (size_t)rows * q_ds_) d_tmp_dyn_.alloc((size_t)rows * q_ds_);
+        if (d_tmp_stat_.n < (size_t)rows * q_ss_) d_tmp_stat_.alloc((size_t)rows * q_ss_);
+        launch_split_queries(q_dev, g_.A, g_.H, d_tmp_dyn_.p, q_ds_, d_tmp_stat_.p, q_ss_, rows, st);
+        MlpDev m2 = mlp_;
+        m2.q_stat = d_tmp_stat_.p;
+        launch_mlp_forward(m2, d_tmp_dyn_.p, rows, out_dev, st, nullptr);
+      } else {
+        launch_mlp_forward(mlp_, q_dev, rows, out_dev, st, range);
+      }
       break;
     case NetMode::kCallback:
       if (cb_host_) {
@@ -555,6 +602,19 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
   pending_trav_ = 0;
 }
 
+void Engine::split_part_queries(int part, hipStream_t st) {
+  if (rows_ <= 0 || tabs_.max_L == 0) return;
+  const int64_t r0 = part_row_[part], nr = part_row_[part + 1] - r0;
+  if (nr <= 0) return;
+  if (info_dev_)  // device-resident epoch: the part's real row range lives on the device, nr is the launch bound
+    launch_split_queries(d_queries_.p, g_.A, g_.H, d_qdyn_.p, q_ds_, d_qstat_.p, q_ss_, nr, st, info_dev_->part_row + part);
+  else
+    launch_split_queries(d_queries_.p + r0 * g_.query_size(), g_.A, g_.H, d_qdyn_.p + r0 * q_ds_, q_ds_, d_qstat_.p + r0 * q_ss_,
+                         q_ss_, nr, st);
+  RBL_HIP_CHECK(hipGetLastError());
+  q_canon_stale_ = false;
+}
+
 void Engine::set_segments(const int (*seg_shape)[kSpSegs]) {
   for (int pt = 0; pt < 4; ++pt)
     for (int k = 0; k < kSpSegs; ++k) {
@@ -576,7 +636,7 @@ void Engine::join_streams() {
 void Engine::end_epoch_device(const SpEpochInfo& info) {
   rows_ = info.rows;
   const double per_row = net_mode_ == NetMode::kMlp
-                             ? 2.0 * ((double)mlp_.n_in * mlp_.n_hidden +
+                             ? 2.0 * ((double)mlp_n_in_true_ * mlp_.n_hidden +
                                       (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
                                       (double)mlp_.n_hidden * mlp_.n_out)
                              : 0.0;
@@ -654,6 +714,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.snapshot = d_snapshot_.p;
   a.root_mean = d_root_mean_.p;
   a.queries = d_queries_.p;
+  a.q_dyn = qsplit_ ? d_qdyn_.p : nullptr;
+  a.q_dyn_stride = q_ds_;
   a.values = d_values_.p;
   a.scratch = d_scratch_.p;
   a.work_stride = work_stride_;
@@ -701,6 +763,10 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
       launch_cfr(a, cnt, block_, lds_bytes_, st);
     }
     if (is_step) last_cfr_kernel_ = which;
+    if (qsplit_) {
+      if (mode == kModeInit || mode == kModeQueries) split_part_queries(part, st);  // the generic kernel wrote canonical rows
+      else if (mode == kModeStep && which == 2) q_canon_stale_ = true;              // the wave kernel wrote dynamic rows only
+    }
     if (is_step) time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
     if (is_step) {
@@ -736,6 +802,29 @@ void Engine::run_net() {
     hipStream_t st = part_stream(part);
     const bool timed = net_mode_ == NetMode::kMlp && timed_now();
     if (timed) time_begin(1, st);
+    if (qsplit_ && net_mode_ == NetMode::kMlp) {  // split layout: dynamic rows in, static rows beside them
+      if (info_dev_) {
+        launch_mlp_forward(mlp_, d_qdyn_.p, nr, d_values_.p, st, info_dev_->part_row + part);
+      } else {
+        MlpDev m2 = mlp_;
+        m2.q_stat = d_qstat_.p + r0 * q_ss_;
+        launch_mlp_forward(m2, d_qdyn_.p + r0 * q_ds_, nr, d_values_.p + r0 * H, st, nullptr);
+      }
+      RBL_HIP_CHECK(hipGetLastError());
+      if (timed) {
+        time_end(1, st);
+        ++stats_.net_launches;
+        if (info_dev_) {
+          ++timed_net_[part];
+        } else {
+          stats_.net_rows += nr;
+          stats_.net_flops += 2.0 * (double)nr *
+                              ((double)mlp_n_in_true_ * mlp_.n_hidden +
+                               (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden + (double)mlp_.n_hidden * mlp_.n_out);
+        }
+      }
+      continue;
+    }
     if (info_dev_) {  // rows [part_row[part], part_row[part + 1]) as written by sp_scan; nr is only the launch bound
       net_forward_dev(d_queries_.p, nr, d_values_.p, st, info_dev_->part_row + part);
       if (timed) {
@@ -751,7 +840,7 @@ void Engine::run_net() {
       ++stats_.net_launches;
       stats_.net_rows += nr;
       stats_.net_flops += 2.0 * (double)nr *
-                          ((double)mlp_.n_in * mlp_.n_hidden + (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
+                          ((double)mlp_n_in_true_ * mlp_.n_hidden + (double)(mlp_.n_layers - 1) * mlp_.n_hidden * mlp_.n_hidden +
                            (double)mlp_.n_hidden * mlp_.n_out);
     }
   }
@@ -1016,6 +1105,11 @@ void Engine::get_queries(float* out) {
   ensure_mirror();
   sync();
   RBL_HIP_CHECK(hipSetDevice(device_));
+  if (rows_ > 0 && qsplit_ && q_canon_stale_) {  // the steps since the last init wrote dynamic rows only: rebuild the canonical rows
+    launch_unsplit_queries(d_queries_.p, g_.A, g_.H, d_qdyn_.p, q_ds_, d_qstat_.p, q_ss_, rows_, stream_);
+    RBL_HIP_CHECK(hipGetLastError());
+    q_canon_stale_ = false;
+  }
   if (rows_ > 0)
     RBL_HIP_CHECK(hipMemcpyAsync(out, d_queries_.p, (size_t)rows_ * g_.query_size() * sizeof(float),
                                  hipMemcpyDeviceToHost, stream_));

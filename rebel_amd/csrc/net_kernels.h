@@ -26,6 +26,10 @@ struct MlpDev {
   const float* ln_w = nullptr;   // [n_layers][n_hidden]
   const float* ln_b = nullptr;   // [n_layers][n_hidden]
   const float* b_out = nullptr;  // [out_tiles*32]
+  // split query layout (tile 5 only; engine.hip): `queries` of a launch are the dynamic rows [rows][q_dyn_stride], q_stat the
+  // static rows [rows][q_stat_stride]; layer 0 is packed for the virtual input row (dyn row | stat row), n_in = the two strides
+  const float* q_stat = nullptr;
+  int q_dyn_stride = 0, q_stat_stride = 0;
 };
 
 // Host-side packing: returns one float blob plus the offsets of the members above (in floats).

@@ -157,9 +157,11 @@ template <int K0C, bool LN>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups,
                                                                     const long long* __restrict__ range) {
+  const float* q_stat = m.q_stat;
   if (range) {  // device-side row range (resident self-play: the host never learns the row counts of an epoch)
     const long long r0 = range[0], r1 = range[1];
-    queries += r0 * m.n_in;
+    queries += r0 * (q_stat ? m.q_dyn_stride : m.n_in);
+    if (q_stat) q_stat += r0 * m.q_stat_stride;
     out += r0 * m.n_out;
     rows = r1 - r0;
     n_groups = (int)((rows + kRows - 1) / kRows);
@@ -221,6 +223,21 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   auto fetch_queries = [&](int grp) {
     const int64_t row = (int64_t)grp * kRows + (wave >> 1) * 16 + j;
     const bool ok = grp < n_groups && row < rows;
+    if (q_stat) {  // split layout: the virtual row is (dynamic row | static row), both strides multiples of 4 floats, so a
+      // thread's four consecutive inputs are one aligned 16-byte load from one of the two
+      const int DS = m.q_dyn_stride, SS = m.q_stat_stride;
+      const int64_t r = ok ? row : 0;
+#pragma unroll
+      for (int ks = 0; ks < K0C; ++ks) {
+        const int k0 = 32 * ks + 8 * g + 4 * (wave & 1);
+        const float* src = k0 < DS ? queries + r * DS + k0 : q_stat + r * SS + (k0 - DS);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && k0 < DS + SS) v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qn[ks][e] = v[e];
+      }
+      return;
+    }
     const float* q = queries + (ok ? row : 0) * n_in;
 #pragma unroll
     for (int ks = 0; ks < K0C; ++ks)

@@ -241,6 +241,57 @@ def test_queries_bit_exact_first_iteration(port):
     assert np.array_equal(e.queries(), seen[0])
 
 
+@pytest.mark.parametrize("d,f", [(1, 6), (1, 4), (2, 3)])
+def test_split_query_layout_equals_canonical(d, f, monkeypatch, port):
+    """With the fused MLP net the one-wavefront CFR kernel writes only the dynamic part of the query rows, contiguously
+    (CfrArgs::q_dyn), and the net reads (dynamic row | static row): the canonical [rows, Q] matrix rebuilt from them equals the
+    matrix of the canonical path (RBL_QSPLIT=0), of a zero-net engine and of the oracle bit for bit.  The net here has a zero
+    output layer, so the two layouts' different summation orders cannot leak into the CFR state."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=16, max_depth=2, linear_update=True, use_cfr=True)
+    rng = np.random.default_rng(5)
+    roots, players = [-1, 2, 5, -1, 7], [0, 1, 0, 1, 1]
+    B = len(roots)
+    H = f ** d
+    beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
+
+    def engine(zero_net):
+        e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=B)
+        if zero_net:
+            e.set_net_zero()
+        else:
+            layers = [(rng.uniform(-1, 1, (256, e.Q)).astype(np.float32), rng.uniform(-1, 1, 256).astype(np.float32)),
+                      (rng.uniform(-.1, .1, (256, 256)).astype(np.float32), np.zeros(256, np.float32))]
+            ln = [(np.ones(256, np.float32), np.zeros(256, np.float32))] * 2
+            e.set_net_mlp(layers, ln, np.zeros((e.H, 256), np.float32), np.zeros(e.H, np.float32))
+        e.reset(roots, players, beliefs)
+        return e
+
+    split = engine(False)
+    monkeypatch.setenv("RBL_QSPLIT", "0")
+    canon = engine(False)
+    monkeypatch.delenv("RBL_QSPLIT")
+    zero = engine(True)
+    seen = []
+    oracles = [port.solver(d, f, orc.make_params(**kw), roots[b], players[b], beliefs[b], orc.NET_CALLBACK,
+                           net_fn=lambda q: (seen.append(q.copy()), np.zeros((q.shape[0], H), np.float32))[1])
+               for b in range(B)]
+    for it in range(7):
+        q0 = split.queries()
+        assert np.array_equal(q0, canon.queries()) and np.array_equal(q0, zero.queries()), it
+        seen.clear()
+        for o in oracles:
+            o.step(it % 2)
+        assert np.array_equal(q0, np.concatenate(seen)), it
+        for e in (split, canon, zero):
+            e.step(it % 2)
+    for lane in range(B):
+        for which in (capi.GET_LAST, capi.GET_REGRETS, capi.GET_SUM):
+            assert np.array_equal(split.get(lane, which), zero.get(lane, which))
+
+
 @pytest.mark.parametrize("linear,optimistic", [(False, False), (True, False), (False, True), (True, True)])
 def test_fictitious_play_variants_bit_exact(linear, optimistic, port):
     """FP solver (subgame_solving.cc:364-506) incl. linear and optimistic averaging, heterogeneous lanes, snapshots."""

@@ -49,7 +49,7 @@ def test_real_net_subgame_elementwise_through_128_iterations(port):
 
     d, f = 1, 6
     # (output scale, iterations through which sigma / average strategy agree to 1e-5, bound on the root values at 128)
-    for scale, exact_until, values_at_128 in ((1.0, 128, 1e-5), (30.0, 16, 1.5e-3)):  # measured 3.7e-9 / 6.1e-4
+    for scale, exact_until, values_at_128 in ((1.0, 128, 1e-5), (30.0, 16, 2e-3)):  # measured <= 5.3e-9 / 5.2e-4 .. 1.0e-3 over three kernels
         net = _net(d, f, scale)
         kw = dict(num_iters=128, max_depth=2, linear_update=True, use_cfr=True)
         e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=1)
@@ -122,9 +122,12 @@ def test_real_net_selfplay_trajectories_at_128_iterations(port):
     print(f"P3 @128: {same_path}/{2 * len(seeds)} games on the same public path; max |dquery| {dq:.2e}, max |dvalue| {dv:.2e}")
     # non-root subgames (peaked beliefs, O(0.3) values from the terminal payoffs) amplify sooner than the root subgame;
     # a policy difference flips a sampled action only when a draw lands inside it
-    # bounds = about twice the values measured on MI355X (48/48 games, 6.5e-4, 1.3e-3; printed above on every run)
+    # What is measured here is a chaotic amplification of ~1e-7 per-call differences: three arithmetically equivalent
+    # net kernels (same products, different summation order / remainder rounding) gave 48/48 games each and
+    # (6.5e-4, 1.3e-3), (9.7e-4, 1.9e-3), (1.6e-3, 3.1e-3) on MI355X.  Bounds = twice the largest observed; the values
+    # are printed above on every run.
     assert same_path >= 2 * len(seeds) - 2, same_path
-    assert dq <= 1.5e-3 and dv <= 3e-3, (dq, dv)
+    assert dq <= 3e-3 and dv <= 6e-3, (dq, dv)
 
 
 def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port):
