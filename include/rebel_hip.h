@@ -151,6 +151,22 @@ int rbl_solver_debug_stamps(rbl_engine* e, long long* out);
 /* developer aid (env RBL_NET_DBG=1): out[1024][16] shader-clock stamps of the last net forward's first 1024 workgroups */
 int rbl_net_debug_stamps(rbl_engine* e, long long* out);
 
+/* ---- full-tree CFR without a dense tabulation (eval_stream.hip): "Solving the game for the full tree" of the reference's
+ * evaluation tool (recursive_eval.cc:269-296: build_solver with max_depth = 100000, CFR::step x subgame_iters,
+ * compute_exploitability2 of get_strategy() along the way) as level-synchronous sweeps over edge-indexed arrays in HBM
+ * (sigma, regrets, sum_strategies [N-1][H], reach and values [N][H]: 58 GB at 2 dice x 6 faces).  CFR only (use_cfr = 1;
+ * linear / DCFR discounts as in SubgameSolvingParams).  rbl_stream_step: n x CFR::step(iteration parity);
+ * rbl_stream_exploitability: of the average strategy; rbl_stream_get: dense [N][H][A] copies (which = RBL_GET_*) for games
+ * that fit (tests).  Errors: rbl_stream_last_error(). ---- */
+typedef struct rbl_stream rbl_stream;
+rbl_stream* rbl_stream_create(int device, int dice, int faces, const rbl_params* params);
+void rbl_stream_destroy(rbl_stream* s);
+int64_t rbl_stream_num_nodes(rbl_stream* s);
+int rbl_stream_step(rbl_stream* s, int n_steps);
+int rbl_stream_exploitability(rbl_stream* s, double out[2]);
+int rbl_stream_get(rbl_stream* s, int which, double* out);
+const char* rbl_stream_last_error(void);
+
 /* ---- self-play lanes: RlRunner (recursive_solving.h:40-86), one per seed (create_cfr_thread, pybind.cc:36-43) ---- */
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,
                                   int sample_leaf);

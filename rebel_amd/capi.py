@@ -26,7 +26,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -130,6 +130,13 @@ def lib():
         "rbl_solver_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_net_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_exploitability_recursive": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, i32p, dp]),
+        "rbl_stream_create": (vp, [C.c_int, C.c_int, C.c_int, C.POINTER(Params)]),
+        "rbl_stream_destroy": (None, [vp]),
+        "rbl_stream_num_nodes": (C.c_int64, [vp]),
+        "rbl_stream_step": (C.c_int, [vp, C.c_int]),
+        "rbl_stream_exploitability": (C.c_int, [vp, dp]),
+        "rbl_stream_get": (C.c_int, [vp, C.c_int, dp]),
+        "rbl_stream_last_error": (C.c_char_p, []),
         "rbl_selfplay_create": (vp, [vp, C.c_int, i32p, C.c_double, C.c_int]),
         "rbl_selfplay_destroy": (None, [vp]),
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
@@ -424,6 +431,48 @@ class Engine:
         s = KernelStats()
         _check(self.L.rbl_engine_stats(self.h, C.byref(s), int(reset)))
         return {k: getattr(s, k) for k, _ in KernelStats._fields_}
+
+
+class StreamSolver:
+    """Full-tree CFR with edge-indexed state in HBM (rbl_stream_*): the reference tool's "Solving the game for the full
+    tree" at sizes whose dense TreeStrategy does not fit."""
+
+    def __init__(self, dice, faces, params, device=0):
+        self.L = lib()
+        self.dice, self.faces = dice, faces
+        self.A, self.H = self.L.rbl_num_actions(dice, faces), self.L.rbl_num_hands(dice, faces)
+        self.h = self.L.rbl_stream_create(device, dice, faces, C.byref(params))
+        if not self.h:
+            raise RebelError((self.L.rbl_stream_last_error() or b"rbl_stream_create failed").decode())
+        self.nodes = int(self.L.rbl_stream_num_nodes(self.h))
+
+    def _ck(self, status):
+        if status != 0:
+            raise RebelError((self.L.rbl_stream_last_error() or b"?").decode())
+
+    def step(self, n=1):
+        self._ck(self.L.rbl_stream_step(self.h, int(n)))
+
+    def exploitability(self):
+        out = np.zeros(2)
+        self._ck(self.L.rbl_stream_exploitability(self.h, _p(out, C.c_double)))
+        return out
+
+    def get(self, which):
+        out = np.zeros((self.nodes, self.H, self.A))
+        self._ck(self.L.rbl_stream_get(self.h, int(which), _p(out, C.c_double)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.rbl_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_rng_draws(seed, rounds, hi, weights, device=0):

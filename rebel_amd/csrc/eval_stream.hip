@@ -201,7 +201,42 @@ __global__ void br_reach_kernel(const SweepArgs a) {
     a.reach[(c0 + k) * H + h] = opp_moves ? up * a.sigma_full[(c0 + k - 1) * H + h] : up;
 }
 
-// values of level `level` from the values of level + 1 (compute_br, :326-355) and terminal payoffs (:80-98, 765-789)
+// Terminal payoffs (compute_expected_terminal_values :80-98, compute_win_probability :765-789) of the liar children of the
+// nodes of level `level`: ONE thread per parent (it knows the bid that was called) builds the match histogram of the
+// opponent's reach at the terminal once and writes the terminal's H values (a thread per (node, hand) would rebuild the
+// histogram H times: 18x the work on half of the tree's nodes).
+__global__ void terminal_value_kernel(const SweepArgs a) {
+  const int64_t n = a.n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= a.n1) return;
+  const int b = a.f_bid[n];
+  if (b == a.liar || b < 0) return;  // terminals have no children; the root's children are all bids
+  const int H = a.H, cnt = a.A - 1 - b;
+  const int64_t z = (int64_t)a.f_cb[n] + cnt - 1;  // the liar child is the last one
+  const int qty = 1 + b / a.faces, face = b % a.faces;
+  const int8_t* m = a.matches + face * H;
+  const double* r = a.reach + z * H;
+  double bins[2 * 8 + 2];
+  const int nbins = 2 * a.dice + 1;
+  for (int q = 0; q < nbins; ++q) bins[q] = 0.0;
+  double s = 0;
+  for (int g = 0; g < H; ++g) {
+    bins[m[g]] += r[g];
+    s += r[g];
+  }
+  for (int q = nbins - 2; q >= 0; --q) bins[q] += bins[q + 1];
+  const bool inverse = ((a.level + 1) & 1) != a.trav;  // mover(z) = the player who did NOT call liar
+  double* out = a.val + z * H;
+  for (int h = 0; h < H; ++h) {
+    const int left = max(0, qty - (int)m[h]);
+    const float pwin = (float)bins[left];  // fp32 truncation (:785)
+    double y = (double)pwin * 2 - s;
+    if (inverse) y *= -1.0;
+    out[h] = y;
+  }
+}
+
+// values of level `level` from the values of level + 1 (compute_br, :326-355); terminal children were valued by
+// terminal_value_kernel
 __global__ void br_value_kernel(const SweepArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int H = a.H;
@@ -209,34 +244,13 @@ __global__ void br_value_kernel(const SweepArgs a) {
   if (n >= a.n1) return;
   const int h = (int)(i % H);
   const int b = a.f_bid[n];
-  if (b == a.liar) return;  // terminals are valued from their parent, which knows the bid that was called
+  if (b == a.liar) return;
   const int cnt = b < 0 ? a.A - 1 : a.A - 1 - b;
   const int64_t c0 = a.f_cb[n];
   const bool mine = (a.level & 1) == a.trav;
   double x = 0.0;
   for (int k = 0; k < cnt; ++k) {
-    double y;
-    if (b >= 0 && k == cnt - 1) {  // the liar child: terminal, bid `b` is checked; mover(z) = the player who did NOT call
-      const int qty = 1 + b / a.faces, face = b % a.faces;
-      const int8_t* m = a.matches + face * H;
-      const double* r = a.reach + (c0 + k) * H;
-      double bins[2 * 8 + 2];
-      const int nbins = 2 * a.dice + 1;
-      for (int q = 0; q < nbins; ++q) bins[q] = 0.0;
-      double s = 0;
-      for (int g = 0; g < H; ++g) {
-        bins[m[g]] += r[g];
-        s += r[g];
-      }
-      for (int q = nbins - 2; q >= 0; --q) bins[q] += bins[q + 1];
-      const int left = max(0, qty - (int)m[h]);
-      const float pwin = (float)bins[left];  // fp32 truncation (:785)
-      y = (double)pwin * 2 - s;
-      if (((a.level + 1) & 1) != a.trav) y *= -1.0;
-      a.val[(c0 + k) * H + h] = y;  // kept for the caller's host-side recombination of shards
-    } else {
-      y = a.val[(c0 + k) * H + h];
-    }
+    const double y = a.val[(c0 + k) * H + h];
     if (mine) {  // first child, then strictly greater (:336-344)
       if (k == 0 || y > x) x = y;
     } else {
@@ -466,6 +480,7 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
       a.n1 = ft.lev_off[lev + 1];
       a.level = lev;
       const int64_t work = (a.n1 - a.n0) * H;
+      hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((a.n1 - a.n0 + 255) / 256)), dim3(256), 0, st, a);
       hipLaunchKernelGGL(br_value_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, a);
     }
     RBL_HIP_CHECK(hipGetLastError());
@@ -491,4 +506,396 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
   }
 }
 
+// =================================================================================================== full-tree CFR, streamed
+// The reference's evaluation tool first solves the WHOLE game with the same solver (recursive_eval.cc:269-296:
+// build_solver with max_depth = 100000, `subgame_iters` steps, exploitability at iterations 2^k).  Its dense state does not
+// fit at 2 dice x 6 faces either; this is the same CFR (subgame_solving.cc:509-670, no pseudo-leaves on a full tree) as
+// level-synchronous sweeps over edge-indexed arrays in HBM -- sigma, regrets, sum_strategies [N-1][H] and two node arrays
+// (reach, values) [N][H], 58 GB for 33.5 M nodes.  One step = opponent reach top-down, values + regret update + regret
+// matching bottom-up (one thread per (node, hand), children walked in ascending order), then the traverser's reach under
+// the new strategy + sum_strategies top-down.  Arithmetic as in cfr_kernels.hip (same operands, same order): on games that
+// fit the engine it is bit-identical to a full-depth lane and to the oracle (tests/test_eval_parity.py).
+namespace {
+
+struct StepArgs {
+  const int8_t* f_bid;
+  const int32_t* f_cb;
+  double *sigma, *regrets, *sums, *avg;  // [N - 1][H]
+  double *reach, *val;                   // [N][H]
+  const int8_t* matches;
+  int64_t n0, n1;
+  int H, A, faces, dice, liar, trav, level;
+  double pos, neg, strat;
+  int steps0, steps1;
+};
+
+__device__ __forceinline__ int child_count(int b, int A) { return b < 0 ? A - 1 : A - 1 - b; }
+
+// ctor (:509-534): uniform sigma, zero regrets, sum_strategies = uniform x the mover's reach under the uniform strategy
+// (:125-149); `reach` holds both players' uniform reach interleaved as [N][2][H] here (val's storage is borrowed for it)
+__global__ void st_init_kernel(const StepArgs a, double* reach2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A), mover = a.level & 1;
+  const int64_t c0 = a.f_cb[n];
+  const double u = 1. / cnt;
+  const double r0 = reach2[(n * 2 + 0) * H + h], r1 = reach2[(n * 2 + 1) * H + h];
+  const double rm = mover == 0 ? r0 : r1;
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t e = (c0 + k - 1) * H + h;
+    a.sigma[e] = u;
+    a.regrets[e] = 0.0;
+    a.sums[e] = u * rm;
+    reach2[((c0 + k) * 2 + 0) * H + h] = mover == 0 ? r0 * u : r0;
+    reach2[((c0 + k) * 2 + 1) * H + h] = mover == 1 ? r1 * u : r1;
+  }
+}
+
+// update_regrets (:542-574) fused with regret matching (:619-634) and the regret discount (:639-650) at the traverser's nodes
+__global__ void st_value_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const bool mine = (a.level & 1) == a.trav;
+  auto child_val = [&](int k) { return a.val[(c0 + k) * H + h]; };  // terminals: terminal_value_kernel
+  double x = 0.0;
+  if (mine) {
+    for (int k = 0; k < cnt; ++k) x += child_val(k) * a.sigma[(c0 + k - 1) * H + h];
+    double s = 0.0;
+    for (int k = 0; k < cnt; ++k) {
+      const int64_t e = (c0 + k - 1) * H + h;
+      double r = a.regrets[e];
+      r += child_val(k);
+      r -= x;
+      const double mm = r > 1e-80 ? r : 1e-80;  // std::max(regret, kRegretSmoothingEps)
+      s += mm;
+      a.sigma[e] = mm;
+      a.regrets[e] = r * (r > 0 ? a.pos : a.neg);
+    }
+    for (int k = 0; k < cnt; ++k) {
+      const int64_t e = (c0 + k - 1) * H + h;
+      a.sigma[e] = a.sigma[e] / s;
+    }
+  } else {
+    for (int k = 0; k < cnt; ++k) x += child_val(k);
+  }
+  a.val[n * H + h] = x;
+}
+
+// traverser's reach under the NEW sigma (:636-638) + sum_strategies (:651-657), top-down
+__global__ void st_sums_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const double r = a.reach[n * H + h];
+  const bool mine = (a.level & 1) == a.trav;
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t e = (c0 + k - 1) * H + h;
+    if (mine) {
+      const double sg = a.sigma[e];
+      double sm = a.sums[e];
+      sm *= a.strat;
+      sm += r * sg;
+      a.sums[e] = sm;
+      a.reach[(c0 + k) * H + h] = r * sg;
+    } else {
+      a.reach[(c0 + k) * H + h] = r;
+    }
+  }
+}
+
+// get_strategy: sum_strategies normalised per (node, hand) on nodes whose mover has stepped (:658-660), else the uniform init
+__global__ void st_average_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const bool untouched = ((a.level & 1) == 0 ? a.steps0 : a.steps1) == 0;
+  double s = 0.0;
+  if (!untouched)
+    for (int k = 0; k < cnt; ++k) s += a.sums[(c0 + k - 1) * H + h];
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t e = (c0 + k - 1) * H + h;
+    a.avg[e] = untouched ? 1. / cnt : a.sums[e] / s;
+  }
+}
+
+}  // namespace
+
+struct StreamSolver {
+  int device;
+  Rules g;
+  rbl_params p;
+  FullTree ft;
+  hipStream_t st = nullptr;
+  DevBuf<int8_t> d_bid, d_matches;
+  DevBuf<int32_t> d_cb;
+  DevBuf<double> d_sigma, d_regrets, d_sums, d_avg, d_reach, d_val;
+  int iter = 0, num_steps[2] = {0, 0};
+  double step_seconds = 0;
+
+  StreamSolver(int dev, int dice, int faces, const rbl_params& params) : device(dev), g(dice, faces), p(params) {
+    if (!p.use_cfr) throw std::runtime_error("stream solver: fictitious play is not available at this scale (use_cfr = 1)");
+    if (g.dice > 8) throw std::runtime_error("stream solver: more than 8 dice");
+    RBL_HIP_CHECK(hipSetDevice(device));
+    RBL_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ft = build_full_tree(g);
+    const int H = g.H;
+    d_bid.upload(ft.bid, st);
+    d_cb.upload(ft.cb, st);
+    std::vector<int8_t> m((size_t)g.faces * H);
+    for (int f = 0; f < g.faces; ++f)
+      for (int h = 0; h < H; ++h) m[(size_t)f * H + h] = (int8_t)g.matches(h, f);
+    d_matches.upload(m, st);
+    const size_t eh = (size_t)std::max<int64_t>(1, ft.N - 1) * H, nh = (size_t)ft.N * H;
+    d_sigma.alloc(eh);
+    d_regrets.alloc(eh);
+    d_sums.alloc(eh);
+    d_avg.alloc(eh);
+    d_reach.alloc(nh);
+    d_val.alloc(std::max(nh, (size_t)0));
+    // ctor: both players' uniform reach top-down through a [N][2][H] scratch (reach + val are exactly that large together)
+    DevBuf<double> reach2;
+    reach2.alloc(2 * nh);
+    std::vector<double> b(2 * (size_t)H, 1.0 / H);
+    RBL_HIP_CHECK(hipMemcpyAsync(reach2.p, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    StepArgs a = args(0);
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      level(a, lev);
+      hipLaunchKernelGGL(st_init_kernel, grid(a), dim3(256), 0, st, a, reach2.p);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+  }
+  ~StreamSolver() {
+    if (st) (void)hipStreamDestroy(st);
+  }
+  int nlev() const { return (int)ft.lev_off.size() - 1; }
+  StepArgs args(int trav) const {
+    StepArgs a{};
+    a.f_bid = d_bid.p;
+    a.f_cb = d_cb.p;
+    a.sigma = d_sigma.p;
+    a.regrets = d_regrets.p;
+    a.sums = d_sums.p;
+    a.avg = d_avg.p;
+    a.reach = d_reach.p;
+    a.val = d_val.p;
+    a.matches = d_matches.p;
+    a.H = g.H;
+    a.A = g.A;
+    a.faces = g.faces;
+    a.dice = g.dice;
+    a.liar = g.liar;
+    a.trav = trav;
+    a.steps0 = num_steps[0];
+    a.steps1 = num_steps[1];
+    return a;
+  }
+  void level(StepArgs& a, int lev) const {
+    a.n0 = ft.lev_off[lev];
+    a.n1 = ft.lev_off[lev + 1];
+    a.level = lev;
+  }
+  static dim3 grid(const StepArgs& a) { return dim3((unsigned)(((a.n1 - a.n0) * a.H + 255) / 256)); }
+  SweepArgs sweep_args(const double* sigma, int trav) const {
+    SweepArgs w{};
+    w.f_bid = d_bid.p;
+    w.f_cb = d_cb.p;
+    w.sigma_full = sigma;
+    w.reach = d_reach.p;
+    w.val = d_val.p;
+    w.matches = d_matches.p;
+    w.H = g.H;
+    w.A = g.A;
+    w.faces = g.faces;
+    w.dice = g.dice;
+    w.liar = g.liar;
+    w.trav = trav;
+    return w;
+  }
+  void root_beliefs() {
+    std::vector<double> b(g.H, 1.0 / g.H);
+    RBL_HIP_CHECK(hipMemcpyAsync(d_reach.p, b.data(), g.H * sizeof(double), hipMemcpyHostToDevice, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+  }
+
+  void step(int t) {  // CFR::step (:577-664) on the full tree
+    RBL_HIP_CHECK(hipSetDevice(device));
+    const int k = num_steps[t];
+    double pos = 1, neg = 1, strat = 1;
+    const double s = k + 1;
+    if (p.linear_update) {
+      pos = neg = strat = s / (s + 1);
+    } else if (p.dcfr) {
+      pos = p.dcfr_alpha >= 5 ? 1 : std::pow(s, p.dcfr_alpha) / (std::pow(s, p.dcfr_alpha) + 1.);
+      neg = p.dcfr_beta <= -5 ? 0 : std::pow(s, p.dcfr_beta) / (std::pow(s, p.dcfr_beta) + 1.);
+      strat = std::pow(s / (s + 1), p.dcfr_gamma);
+    }
+    // opponent reach under sigma, top-down
+    root_beliefs();
+    SweepArgs w = sweep_args(d_sigma.p, t);
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      w.n0 = ft.lev_off[lev];
+      w.n1 = ft.lev_off[lev + 1];
+      w.level = lev;
+      hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w);
+    }
+    StepArgs a = args(t);
+    a.pos = pos;
+    a.neg = neg;
+    a.strat = strat;
+    for (int lev = nlev() - 2; lev >= 0; --lev) {
+      level(a, lev);
+      w.n0 = a.n0;
+      w.n1 = a.n1;
+      w.level = lev;
+      hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((w.n1 - w.n0 + 255) / 256)), dim3(256), 0, st, w);
+      hipLaunchKernelGGL(st_value_kernel, grid(a), dim3(256), 0, st, a);
+    }
+    root_beliefs();  // the traverser's beliefs at the root; its reach under the new sigma follows top-down
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      level(a, lev);
+      hipLaunchKernelGGL(st_sums_kernel, grid(a), dim3(256), 0, st, a);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+    ++num_steps[t];
+    ++iter;
+  }
+
+  void average() {
+    StepArgs a = args(0);
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      level(a, lev);
+      hipLaunchKernelGGL(st_average_kernel, grid(a), dim3(256), 0, st, a);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+  }
+
+  // compute_exploitability2 (:802-816) of `sigma` (an edge-indexed strategy on this device)
+  void exploitability(const double* sigma, double out2[2]) {
+    std::vector<double> root(g.H);
+    for (int t = 0; t < 2; ++t) {
+      root_beliefs();
+      SweepArgs w = sweep_args(sigma, t);
+      for (int lev = 0; lev + 1 < nlev(); ++lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w);
+      }
+      for (int lev = nlev() - 2; lev >= 0; --lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((w.n1 - w.n0 + 255) / 256)), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(br_value_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w);
+      }
+      RBL_HIP_CHECK(hipGetLastError());
+      RBL_HIP_CHECK(hipMemcpyAsync(root.data(), d_val.p, g.H * sizeof(double), hipMemcpyDeviceToHost, st));
+      RBL_HIP_CHECK(hipStreamSynchronize(st));
+      double sum = 0;
+      for (int h = 0; h < g.H; ++h) sum += root[h];
+      out2[t] = sum / g.H;
+    }
+  }
+
+  // edge-indexed [N-1][H] device array -> the reference's dense TreeStrategy [N][H][A] on the host (small games: tests)
+  void dense(const double* edge_dev, double* out) {
+    const int H = g.H, A = g.A;
+    std::vector<double> e((size_t)(ft.N - 1) * H);
+    RBL_HIP_CHECK(hipMemcpyAsync(e.data(), edge_dev, e.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    std::fill(out, out + (size_t)ft.N * H * A, 0.0);
+    for (int64_t n = 0; n < ft.N; ++n) {
+      const int b = ft.bid[n];
+      if (b == g.liar) continue;
+      int lo, hi;
+      g.bid_range(b, &lo, &hi);
+      for (int k = 0; k < hi - lo; ++k)
+        for (int h = 0; h < H; ++h) out[((size_t)n * H + h) * A + lo + k] = e[(size_t)(ft.cb[n] + k - 1) * H + h];
+    }
+  }
+};
+
 }  // namespace rbl
+
+// ---------------------------------------------------------------------------------------------- C ABI of the stream solver
+struct rbl_stream {
+  rbl::StreamSolver impl;
+  rbl_stream(int dev, int d, int f, const rbl_params& p) : impl(dev, d, f, p) {}
+};
+
+namespace {
+thread_local std::string g_stream_err;
+template <class F>
+int stream_guard(F&& f) {
+  try {
+    f();
+    return 0;
+  } catch (const std::exception& ex) {
+    g_stream_err = ex.what();
+    return 1;
+  }
+}
+}  // namespace
+
+extern "C" {
+const char* rbl_stream_last_error(void) { return g_stream_err.c_str(); }
+rbl_stream* rbl_stream_create(int device, int dice, int faces, const rbl_params* params) {
+  rbl_stream* s = nullptr;
+  if (!params || stream_guard([&] { s = new rbl_stream(device, dice, faces, *params); })) return nullptr;
+  return s;
+}
+void rbl_stream_destroy(rbl_stream* s) { delete s; }
+int64_t rbl_stream_num_nodes(rbl_stream* s) { return s ? s->impl.ft.N : -1; }
+int rbl_stream_step(rbl_stream* s, int n_steps) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    for (int i = 0; i < n_steps; ++i) s->impl.step(s->impl.iter % 2);
+    RBL_HIP_CHECK(hipStreamSynchronize(s->impl.st));
+  });
+}
+int rbl_stream_exploitability(rbl_stream* s, double out[2]) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    s->impl.average();
+    s->impl.exploitability(s->impl.d_avg.p, out);
+  });
+}
+int rbl_stream_get(rbl_stream* s, int which, double* out) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    if (s->impl.ft.N > (1 << 22)) throw std::runtime_error("rbl_stream_get: the dense strategy of this game does not fit (that is the point)");
+    switch (which) {
+      case RBL_GET_AVERAGE: s->impl.average(); s->impl.dense(s->impl.d_avg.p, out); break;
+      case RBL_GET_LAST: s->impl.dense(s->impl.d_sigma.p, out); break;
+      case RBL_GET_REGRETS: s->impl.dense(s->impl.d_regrets.p, out); break;
+      case RBL_GET_SUM: s->impl.dense(s->impl.d_sums.p, out); break;
+      default: throw std::runtime_error("rbl_stream_get: bad selector");
+    }
+  });
+}
+}

@@ -163,6 +163,31 @@ def test_recursive_eval_tool(tmp_path):
     assert set(ev) == set(d) and abs(float(ev["full_tree"])) < 1e-6  # EV of the full-tree strategy against itself
 
 
+@pytest.mark.parametrize("d,f,iters,variant", [(1, 4, 64, "linear"), (1, 5, 33, "plain"), (2, 2, 40, "linear"), (1, 6, 17, "dcfr"),
+                                               (1, 4, 1, "linear")])
+def test_stream_solver_bit_exact(d, f, iters, variant, port):
+    """rbl_stream_*: full-tree CFR as level-synchronous sweeps over edge-indexed arrays (the reference tool's "Solving the
+    game for the full tree", recursive_eval.cc:269-296) == the oracle's full-depth CFR solver: regrets, sum / last / average
+    strategies and the exploitability trace, bit for bit."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    kw = dict(num_iters=iters, max_depth=100000, use_cfr=True, linear_update=variant == "linear")
+    if variant == "dcfr":
+        kw.update(dcfr=True, dcfr_alpha=1.5, dcfr_beta=0.5, dcfr_gamma=2.0)
+    s = capi.StreamSolver(d, f, capi.make_params(**kw))
+    o = port.solver(d, f, orc.make_params(**kw), net=orc.NET_NONE)
+    assert s.nodes == o.N
+    for it in range(iters):
+        s.step(1)
+        o.step(it % 2)
+        if ((it + 1) & it) == 0 or it + 1 == iters:
+            assert np.array_equal(s.exploitability(), port.exploitability2(d, f, o.get(orc.GET_AVERAGE))), it
+    for ours, theirs in ((capi.GET_REGRETS, orc.GET_REGRETS), (capi.GET_SUM, orc.GET_SUM), (capi.GET_LAST, orc.GET_LAST),
+                         (capi.GET_AVERAGE, orc.GET_AVERAGE)):
+        assert np.array_equal(s.get(ours), o.get(theirs)), ours
+
+
 def test_recursive_eval_tool_vs_reference_binary():
     """scripts/recursive_eval.py against the UNMODIFIED reference tool (oracle/_ref/recursive_eval = recursive_eval.cc built by
     oracle/Makefile; golden stdout in tests/golden/recursive_eval_1d4f.json, made by make_recursive_eval_golden.py): the
