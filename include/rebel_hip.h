@@ -57,7 +57,8 @@ typedef void (*rbl_net_fn)(void* user, const float* queries, int64_t rows, int64
 typedef void (*rbl_example_fn)(void* user, int64_t n, const int32_t* lanes, const float* queries, int64_t qsize,
                                const float* values, int64_t n_out);
 
-enum { RBL_GET_AVERAGE = 0, RBL_GET_LAST = 1, RBL_GET_REGRETS = 2, RBL_GET_SUM = 3 };
+enum { RBL_GET_AVERAGE = 0, RBL_GET_LAST = 1, RBL_GET_REGRETS = 2, RBL_GET_SUM = 3,
+       RBL_GET_SAMPLED = 4, RBL_GET_FINAL = 5 /* rbl_stream_get only: the last sampled repeat, the mean of the repeats */ };
 
 const char* rbl_last_error(void);
 int rbl_device_count(void);
@@ -166,6 +167,16 @@ int rbl_stream_step(rbl_stream* s, int n_steps);
 int rbl_stream_exploitability(rbl_stream* s, double out[2]);
 int rbl_stream_get(rbl_stream* s, int which, double* out);
 const char* rbl_stream_last_error(void);
+/* "Recursive solving" of the same tool (recursive_eval.cc:320-388) on the same arrays.  rbl_stream_sampled_add: one repeat =
+ * compute_sampled_strategy_recursive_to_leaf(game, params of `e`, net of `e`, seed, root_only = false)
+ * (recursive_solving.cc:301-327; every subgame of a recursion level is a lane of `e`, act_iteration drawn per subgame in the
+ * reference's construction order), added to summed_strategy / summed_reach (float32 like the reference's tensors,
+ * recursive_eval.cc:136-160, 343-349).  rbl_stream_sampled_eval: final_strategy = summed_strategy / (summed_reach + 1e-6),
+ * its compute_exploitability2 and compute_ev2(full-tree average strategy of `s`, final_strategy) (:352-371).
+ * rbl_stream_sampled_reset: forget the repeats. */
+int rbl_stream_sampled_reset(rbl_stream* s);
+int rbl_stream_sampled_add(rbl_stream* s, rbl_engine* e, int seed);
+int rbl_stream_sampled_eval(rbl_stream* s, double exploitability[2], double ev_of_full[2]);
 
 /* ---- self-play lanes: RlRunner (recursive_solving.h:40-86), one per seed (create_cfr_thread, pybind.cc:36-43) ---- */
 rbl_selfplay* rbl_selfplay_create(rbl_engine* e, int n_lanes, const int32_t* seeds, double random_action_prob,

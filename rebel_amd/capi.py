@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("REBEL_HIP_LIB") or os.path.join(HERE, "librebel_hip.so")  # override: A/B builds
 
 GET_AVERAGE, GET_LAST, GET_REGRETS, GET_SUM = 0, 1, 2, 3
+GET_SAMPLED, GET_FINAL = 4, 5  # StreamSolver.get only
 
 NET_FN = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int64, C.POINTER(C.c_float), C.c_int64,
                      C.c_void_p)
@@ -26,7 +27,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -137,6 +138,9 @@ def lib():
         "rbl_stream_exploitability": (C.c_int, [vp, dp]),
         "rbl_stream_get": (C.c_int, [vp, C.c_int, dp]),
         "rbl_stream_last_error": (C.c_char_p, []),
+        "rbl_stream_sampled_reset": (C.c_int, [vp]),
+        "rbl_stream_sampled_add": (C.c_int, [vp, vp, C.c_int]),
+        "rbl_stream_sampled_eval": (C.c_int, [vp, dp, dp]),
         "rbl_selfplay_create": (vp, [vp, C.c_int, i32p, C.c_double, C.c_int]),
         "rbl_selfplay_destroy": (None, [vp]),
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
@@ -462,6 +466,19 @@ class StreamSolver:
         out = np.zeros((self.nodes, self.H, self.A))
         self._ck(self.L.rbl_stream_get(self.h, int(which), _p(out, C.c_double)))
         return out
+
+    def sampled_reset(self):
+        self._ck(self.L.rbl_stream_sampled_reset(self.h))
+
+    def sampled_add(self, engine, seed):
+        """One repeat of the tool's "Recursive solving" on the lanes of `engine` (max_depth = mdp_depth, its net)."""
+        self._ck(self.L.rbl_stream_sampled_add(self.h, engine.h, int(seed)))
+
+    def sampled_eval(self):
+        """(exploitability2 of the mean of the repeats, compute_ev2(full-tree average, mean of the repeats))."""
+        ex, ev = np.zeros(2), np.zeros(2)
+        self._ck(self.L.rbl_stream_sampled_eval(self.h, _p(ex, C.c_double), _p(ev, C.c_double)))
+        return ex, ev
 
     def close(self):
         if self.h:

@@ -105,7 +105,7 @@ class Engine {
   }
   // read-only view of the solver state for the streaming evaluation (eval_stream.hip); valid until the next reset()
   struct EvalView {
-    const double *sums, *sigma, *beliefs;
+    const double *sums, *sigma, *snapshot, *beliefs;
     const int *lane_shape, *lane_player;
     const ShapeDev* shapes;
     const int *parent, *cb, *ce, *depth, *leaves;
@@ -113,7 +113,7 @@ class Engine {
     bool use_cfr;
   };
   EvalView eval_view() const {
-    return EvalView{d_sums_.p,   d_sigma_.p, d_beliefs_.p, d_lane_shape_.p, d_lane_player_.p, d_shapes_.p, d_parent_.p,
+    return EvalView{d_sums_.p,   d_sigma_.p, d_snapshot_.p, d_beliefs_.p, d_lane_shape_.p, d_lane_player_.p, d_shapes_.p, d_parent_.p,
                     d_cb_.p,     d_ce_.p,    d_depth_.p,   d_leaves_.p,     {num_steps_[0], num_steps_[1]}, p_.use_cfr != 0};
   }
   // cfr_rows_kernel<GS> (2 dice x 6 faces) is launched per size-sorted segment of a part: device-resident epochs get the
@@ -250,6 +250,7 @@ class Engine {
 
 // eval_stream.hip: compute_strategy_recursive_to_leaf + compute_exploitability2 with the full-tree strategy kept on the
 // device, edge-indexed (no dense [N][H][A] tabulation); see include/rebel_hip.h: rbl_exploitability_recursive
+Engine& engine_impl(rbl_engine* e);  // the engine behind a C handle (engine.hip)
 void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
                               double* stats);
 

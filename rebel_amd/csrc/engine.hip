@@ -1650,6 +1650,9 @@ struct rbl_engine {
   rbl_engine(int device, int dice, int faces, const rbl_params& p, int max_lanes)
       : impl(device, dice, faces, p, max_lanes) {}
 };
+namespace rbl {
+Engine& engine_impl(rbl_engine* e) { return e->impl; }
+}  // namespace rbl
 struct rbl_selfplay {
   rbl::SelfPlay impl;
   rbl_selfplay(rbl::Engine* e, int n, const int32_t* seeds, double rap, bool leaf) : impl(e, n, seeds, rap, leaf) {}

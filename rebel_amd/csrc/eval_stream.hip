@@ -26,7 +26,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <random>
 
 #include "engine.h"
 
@@ -264,19 +266,22 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-}  // namespace
+// The recursion of compute_strategy_with_solver_to_leaf (recursive_solving.cc:76-134), level by level: every subgame of a
+// level is a lane of `e`; the scatter kernel writes its strategy to the full tree's edges (d_sigma, [N - 1][H]) and builds the
+// next frontier.  act == nullptr: the average strategy after num_iters (compute_strategy_recursive_to_leaf, :289-299);
+// otherwise (*act)[node] is the act_iteration of the subgame rooted at `node` and the strategy is the solver's
+// get_sampling_strategy() at that iteration, which also carries the beliefs down (use_sampling_strategy = true, :117-124).
+struct RecursionStats {
+  int64_t n_subgames = 0, n_owned = 0;
+  int levels = 0;
+};
 
-// out2: exploitabilities of the two players (n_shards == 1, NaN otherwise).  top_values (optional): [2][M][H] best-response
-// values per traverser of the M nodes of depth <= max_depth (M = size of unroll_tree(game, root, max_depth)); top_owner
-// (optional): [M] shard that owns the subtree of each non-terminal depth-max_depth node, -1 for every other node.
-// stats (optional): [8] = {nodes, subgames solved, levels, solve s, sweep s, bytes of the strategy, frontier items, M}.
-void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
-                              double* stats) {
+RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb, double* d_sigma, int shard, int n_shards,
+                              const std::vector<int16_t>* act, int32_t* top_owner) {
   const Rules& g = e.rules();
   const ShapeTables& tb = e.tables();
-  const int H = g.H, A = g.A;
+  const int H = g.H;
   if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("exploitability_recursive: bad shard");
-  if (g.dice > 8) throw std::runtime_error("exploitability_recursive: more than 8 dice");
   RBL_HIP_CHECK(hipSetDevice(e.device()));
   hipStream_t st = e.stream();
   const int D = e.params().max_depth;
@@ -286,23 +291,9 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
     throw std::runtime_error("exploitability_recursive: subgames of depth " + std::to_string(D) +
                              " do not fit the scatter kernel's LDS image (" + std::to_string(lds) + " bytes)");
   RBL_HIP_CHECK(hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-
-  const double t0 = now_s();
-  const FullTree ft = build_full_tree(g);
-  DevBuf<int8_t> d_bid, d_matches;
-  DevBuf<int32_t> d_cb, d_node[2], d_lane_node, d_tag[2], d_lane_tag;
+  DevBuf<int32_t> d_node[2], d_lane_node, d_tag[2], d_lane_tag;
   DevBuf<int64_t> d_lane_out;
-  DevBuf<double> d_sigma, d_bel[2];
-  d_bid.upload(ft.bid, st);
-  d_cb.upload(ft.cb, st);
-  d_sigma.alloc((size_t)std::max<int64_t>(1, ft.N - 1) * H);
-  RBL_HIP_CHECK(hipMemsetAsync(d_sigma.p, 0, d_sigma.n * sizeof(double), st));
-  {
-    std::vector<int8_t> m((size_t)g.faces * H);
-    for (int f = 0; f < g.faces; ++f)
-      for (int h = 0; h < H; ++h) m[(size_t)f * H + h] = (int8_t)g.matches(h, f);
-    d_matches.upload(m, st);
-  }
+  DevBuf<double> d_bel[2];
 
   // ------------------------------------------------------------------ recursion, level by level
   std::vector<int32_t> f_node{0};
@@ -316,7 +307,7 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
   int cur = 0, level = 0;
   int64_t n_subgames = 0, n_owned = 0;
   const int maxB = e.max_lanes();
-  std::vector<int32_t> bids(maxB), players(maxB), lane_node(maxB);
+  std::vector<int32_t> bids(maxB), players(maxB), lane_node(maxB), lane_act(maxB);
   std::vector<int32_t> lane_tag(maxB);
   std::vector<int64_t> lane_out(maxB);
   std::vector<double> bel_host((size_t)maxB * 2 * H);
@@ -336,23 +327,28 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
       RBL_HIP_CHECK(hipMemcpyAsync(bel_host.data(), d_bel[cur].p + base * 2 * H, (size_t)B * 2 * H * sizeof(double),
                                    hipMemcpyDeviceToHost, st));
       RBL_HIP_CHECK(hipStreamSynchronize(st));
+      int steps = act ? 0 : -1;
       for (int i = 0; i < B; ++i) {
         bids[i] = ft.bid[f_node[base + i]];
         players[i] = player;
         lane_node[i] = f_node[base + i];
         lane_tag[i] = f_tag[base + i];
         lane_out[i] = out_off[base + i];
+        if (act) {
+          lane_act[i] = (*act)[f_node[base + i]];
+          steps = std::max(steps, lane_act[i]);
+        }
       }
-      e.reset(B, bids.data(), players.data(), bel_host.data(), nullptr);
-      e.multistep(-1);
+      e.reset(B, bids.data(), players.data(), bel_host.data(), act ? lane_act.data() : nullptr);
+      e.multistep(steps);
       e.sync();  // every lane part (stream) of the engine has finished before the scatter kernel reads the lanes
       const Engine::EvalView v = e.eval_view();
       d_lane_node.upload(std::vector<int32_t>(lane_node.begin(), lane_node.begin() + B), st);
       d_lane_tag.upload(std::vector<int32_t>(lane_tag.begin(), lane_tag.begin() + B), st);
       d_lane_out.upload(std::vector<int64_t>(lane_out.begin(), lane_out.begin() + B), st);
       ScatterArgs a{};
-      a.src = v.use_cfr ? v.sums : v.sigma;
-      a.normalise = v.use_cfr ? 1 : 0;
+      a.src = act ? v.snapshot : (v.use_cfr ? v.sums : v.sigma);
+      a.normalise = !act && v.use_cfr ? 1 : 0;
       a.steps0 = v.num_steps[0];
       a.steps1 = v.num_steps[1];
       a.emax = e.emax();
@@ -366,8 +362,8 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
       a.ce = v.ce;
       a.depth = v.depth;
       a.leaves = v.leaves;
-      a.f_cb = d_cb.p;
-      a.sigma_full = d_sigma.p;
+      a.f_cb = d_cb;
+      a.sigma_full = d_sigma;
       a.lane_node = d_lane_node.p;
       a.lane_out = d_lane_out.p;
       a.lane_tag = d_lane_tag.p;
@@ -442,6 +438,43 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
     cur = nxt;
     ++level;
   }
+  RecursionStats rs;
+  rs.n_subgames = n_subgames;
+  rs.n_owned = n_owned;
+  rs.levels = level;
+  return rs;
+}
+
+}  // namespace
+
+// out2: exploitabilities of the two players (n_shards == 1, NaN otherwise).  top_values (optional): [2][M][H] best-response
+// values per traverser of the M nodes of depth <= max_depth (M = size of unroll_tree(game, root, max_depth)); top_owner
+// (optional): [M] shard that owns the subtree of each non-terminal depth-max_depth node, -1 for every other node.
+// stats (optional): [8] = {nodes, subgames solved, levels, solve s, sweep s, bytes of the strategy, frontier items, M}.
+void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
+                              double* stats) {
+  const Rules& g = e.rules();
+  const int H = g.H, A = g.A;
+  if (g.dice > 8) throw std::runtime_error("exploitability_recursive: more than 8 dice");
+  RBL_HIP_CHECK(hipSetDevice(e.device()));
+  hipStream_t st = e.stream();
+  const int D = e.params().max_depth;
+  const double t0 = now_s();
+  const FullTree ft = build_full_tree(g);
+  DevBuf<int8_t> d_bid, d_matches;
+  DevBuf<int32_t> d_cb;
+  DevBuf<double> d_sigma;
+  d_bid.upload(ft.bid, st);
+  d_cb.upload(ft.cb, st);
+  d_sigma.alloc((size_t)std::max<int64_t>(1, ft.N - 1) * H);
+  RBL_HIP_CHECK(hipMemsetAsync(d_sigma.p, 0, d_sigma.n * sizeof(double), st));
+  {
+    std::vector<int8_t> m((size_t)g.faces * H);
+    for (int f = 0; f < g.faces; ++f)
+      for (int h = 0; h < H; ++h) m[(size_t)f * H + h] = (int8_t)g.matches(h, f);
+    d_matches.upload(m, st);
+  }
+  const RecursionStats rs = recursive_fill(e, ft, d_cb.p, d_sigma.p, shard, n_shards, nullptr, top_owner);
   const double t1 = now_s();
 
   // ------------------------------------------------------------------ best-response sweeps over the full tree
@@ -496,12 +529,12 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
   const double t2 = now_s();
   if (stats) {
     stats[0] = (double)ft.N;
-    stats[1] = (double)n_subgames;
-    stats[2] = (double)level;
+    stats[1] = (double)rs.n_subgames;
+    stats[2] = (double)rs.levels;
     stats[3] = t1 - t0;
     stats[4] = t2 - t1;
     stats[5] = (double)d_sigma.n * sizeof(double);
-    stats[6] = (double)n_owned;
+    stats[6] = (double)rs.n_owned;
     stats[7] = (double)M;
   }
 }
@@ -642,6 +675,122 @@ __global__ void st_average_kernel(const StepArgs a) {
   }
 }
 
+// ---- sampled repeats (recursive_eval.cc:136-160, 336-363).  The reference keeps float32 tensors summed_strategy
+// [N][H][A] and summed_reach [N][H][1]; the weight of (node, hand) in a repeat is the reach of the node's mover under that
+// repeat's strategy from uniform beliefs (compute_stategy_stats: subgame_solving.cc:839-842), computed in fp64 from the fp64
+// strategy and THEN rounded to float; the strategy is rounded to float on its own (tree_strategy_to_tensor :82-96); product
+// and running sums are float operations (no contraction: -ffp-contract=off).
+struct AccArgs {
+  const int8_t* f_bid;
+  const int32_t* f_cb;
+  const double* samp;  // [N - 1][H] this repeat's strategy
+  double *r0, *r1;     // [N][H] reach of player 0 / 1 under it
+  float* sstrat;       // [N - 1][H]
+  float* sreach;       // [N][H]
+  double* fin;         // [N - 1][H]
+  int64_t n0, n1;
+  int H, A, liar, level;
+};
+
+__global__ void sm_accumulate_kernel(const AccArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;  // a terminal's row of the strategy is zero: nothing to add
+  const int cnt = child_count(b, a.A), mover = a.level & 1;
+  const int64_t c0 = a.f_cb[n];
+  const double r0 = a.r0[n * H + h], r1 = a.r1[n * H + h];
+  const float w = (float)(mover == 0 ? r0 : r1);
+  a.sreach[n * H + h] += w;
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t e = (c0 + k - 1) * H + h;
+    const double s = a.samp[e];
+    const float prod = (float)s * w;
+    a.sstrat[e] += prod;
+    a.r0[(c0 + k) * H + h] = mover == 0 ? r0 * s : r0;
+    a.r1[(c0 + k) * H + h] = mover == 1 ? r1 * s : r1;
+  }
+}
+
+// final_strategy = summed_strategy / (summed_reach + 1e-6), float division, then widened (:352-353)
+__global__ void sm_final_kernel(const AccArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const float den = a.sreach[n * H + h] + 1e-6f;
+  for (int k = 0; k < cnt; ++k) {
+    const int64_t e = (c0 + k - 1) * H + h;
+    a.fin[e] = (double)(a.sstrat[e] / den);
+  }
+}
+
+// compute_ev (:931-973): player 0 follows `sigma_own` at its nodes, values of the other player's nodes are sums
+__global__ void ev_value_kernel(const SweepArgs a, const double* sigma_own) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const bool mine = (a.level & 1) == a.trav;
+  double x = 0.0;
+  for (int k = 0; k < cnt; ++k) {
+    const double y = a.val[(c0 + k) * H + h];
+    if (mine) x += sigma_own[(c0 + k - 1) * H + h] * y;
+    else x += y;
+  }
+  a.val[n * H + h] = x;
+}
+
+// act_iteration of every subgame of the recursion, drawn in the order the reference constructs its solvers
+// (recursive_solving.cc:301-327 + :96-131: a subgame, then depth-first each of its pseudo-leaves in the partial tree's
+// BFS order = ascending full-tree id).  The weights emulate linear averaging: even iterations only, weight i / 2 + 1.
+// std::discrete_distribution keeps no state between draws, so one instance stands for the reference's per-solver ones.
+std::vector<int16_t> draw_act_iterations(const FullTree& ft, const Rules& g, int D, int num_iters, int seed) {
+  if (num_iters > 32767) throw std::runtime_error("sampled recursion: num_iters above 32767");
+  std::vector<int16_t> act((size_t)ft.N, (int16_t)-1);
+  std::mt19937 gen(seed);
+  std::vector<double> w;
+  for (int i = 0; i < num_iters; ++i) w.push_back(i % 2 ? 0.0 : (i / 2. + 1));
+  std::discrete_distribution<int> dist(w.begin(), w.end());
+  std::vector<std::vector<int32_t>> scratch;  // two node lists per recursion depth
+  std::function<void(int32_t, int)> visit = [&](int32_t root, int rd) {
+    act[root] = (int16_t)dist(gen);
+    if (scratch.size() < 2 * (size_t)rd + 2) scratch.resize(2 * (size_t)rd + 2);
+    int cur = 2 * rd, nxt = 2 * rd + 1;
+    scratch[cur].assign(1, root);
+    for (int d = 0; d < D && !scratch[cur].empty(); ++d) {
+      scratch[nxt].clear();
+      for (size_t j = 0; j < scratch[cur].size(); ++j) {
+        const int32_t n = scratch[cur][j];
+        const int b = ft.bid[n];
+        if (b == g.liar) continue;
+        const int cnt = b < 0 ? g.A - 1 : g.A - 1 - b;
+        for (int k = 0; k < cnt; ++k) scratch[nxt].push_back(ft.cb[n] + k);
+      }
+      std::swap(cur, nxt);
+    }
+    for (size_t j = 0; j < scratch[cur].size(); ++j) {  // visit() below may grow `scratch`: index, do not hold references
+      const int32_t n = scratch[cur][j];
+      if (ft.bid[n] != g.liar) visit(n, rd + 1);
+    }
+  };
+  visit(0, 0);
+  return act;
+}
+
 }  // namespace
 
 struct StreamSolver {
@@ -653,6 +802,10 @@ struct StreamSolver {
   DevBuf<int8_t> d_bid, d_matches;
   DevBuf<int32_t> d_cb;
   DevBuf<double> d_sigma, d_regrets, d_sums, d_avg, d_reach, d_val;
+  DevBuf<double> d_samp, d_final;  // sampled repeats: the current repeat's strategy, the reach-weighted mean of all
+  DevBuf<float> d_sstrat, d_sreach;
+  int n_samples = 0;
+  double sample_seconds = 0;
   int iter = 0, num_steps[2] = {0, 0};
   double step_seconds = 0;
 
@@ -822,6 +975,105 @@ struct StreamSolver {
     }
   }
 
+
+  // ---- "Recursive solving" of the reference tool (recursive_eval.cc:320-388) without dense tensors
+  void sampled_reset() {
+    RBL_HIP_CHECK(hipSetDevice(device));
+    const size_t eh = (size_t)std::max<int64_t>(1, ft.N - 1) * g.H, nh = (size_t)ft.N * g.H;
+    if (!d_samp.p) {
+      d_samp.alloc(eh);
+      d_final.alloc(eh);
+      d_sstrat.alloc(eh);
+      d_sreach.alloc(nh);
+    }
+    RBL_HIP_CHECK(hipMemsetAsync(d_sstrat.p, 0, eh * sizeof(float), st));
+    RBL_HIP_CHECK(hipMemsetAsync(d_sreach.p, 0, nh * sizeof(float), st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    n_samples = 0;
+  }
+  AccArgs acc_args() const {
+    AccArgs a{};
+    a.f_bid = d_bid.p;
+    a.f_cb = d_cb.p;
+    a.samp = d_samp.p;
+    a.r0 = d_reach.p;
+    a.r1 = d_val.p;
+    a.sstrat = d_sstrat.p;
+    a.sreach = d_sreach.p;
+    a.fin = d_final.p;
+    a.H = g.H;
+    a.A = g.A;
+    a.liar = g.liar;
+    return a;
+  }
+  // one repeat: compute_sampled_strategy_recursive_to_leaf(game, params, net, seed, root_only = false) on the lanes of `e`
+  // (its max_depth is the tool's mdp_depth, its net the value net), then summed_strategy / summed_reach
+  void sampled_add(Engine& e, int seed) {
+    if (e.device() != device || e.rules().dice != g.dice || e.rules().faces != g.faces)
+      throw std::runtime_error("sampled_add: the engine is for another device or game");
+    if (!d_samp.p) sampled_reset();
+    const double t0 = now_s();
+    const std::vector<int16_t> act = draw_act_iterations(ft, g, e.params().max_depth, e.params().num_iters, seed);
+    recursive_fill(e, ft, d_cb.p, d_samp.p, 0, 1, &act, nullptr);
+    RBL_HIP_CHECK(hipSetDevice(device));
+    std::vector<double> b(g.H, 1.0 / g.H);
+    RBL_HIP_CHECK(hipMemcpyAsync(d_reach.p, b.data(), g.H * sizeof(double), hipMemcpyHostToDevice, st));
+    RBL_HIP_CHECK(hipMemcpyAsync(d_val.p, b.data(), g.H * sizeof(double), hipMemcpyHostToDevice, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    AccArgs a = acc_args();
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      a.n0 = ft.lev_off[lev];
+      a.n1 = ft.lev_off[lev + 1];
+      a.level = lev;
+      hipLaunchKernelGGL(sm_accumulate_kernel, dim3((unsigned)(((a.n1 - a.n0) * g.H + 255) / 256)), dim3(256), 0, st, a);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    ++n_samples;
+    sample_seconds += now_s() - t0;
+  }
+  void sampled_final() {
+    if (!n_samples) throw std::runtime_error("sampled_final: no repeats were added");
+    AccArgs a = acc_args();
+    for (int lev = 0; lev + 1 < nlev(); ++lev) {
+      a.n0 = ft.lev_off[lev];
+      a.n1 = ft.lev_off[lev + 1];
+      a.level = lev;
+      hipLaunchKernelGGL(sm_final_kernel, dim3((unsigned)(((a.n1 - a.n0) * g.H + 255) / 256)), dim3(256), 0, st, a);
+    }
+    RBL_HIP_CHECK(hipGetLastError());
+  }
+
+  // compute_ev2 (:975-982): {EV of s1 as player 0 against s2, -(EV of s2 as player 0 against s1)}
+  void ev2(const double* s1, const double* s2, double out2[2]) {
+    std::vector<double> root(g.H);
+    for (int t = 0; t < 2; ++t) {
+      const double* own = t == 0 ? s1 : s2;
+      const double* opp = t == 0 ? s2 : s1;
+      root_beliefs();
+      SweepArgs w = sweep_args(opp, 0);
+      for (int lev = 0; lev + 1 < nlev(); ++lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w);
+      }
+      for (int lev = nlev() - 2; lev >= 0; --lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((w.n1 - w.n0 + 255) / 256)), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(ev_value_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w, own);
+      }
+      RBL_HIP_CHECK(hipGetLastError());
+      RBL_HIP_CHECK(hipMemcpyAsync(root.data(), d_val.p, g.H * sizeof(double), hipMemcpyDeviceToHost, st));
+      RBL_HIP_CHECK(hipStreamSynchronize(st));
+      double sum = 0;
+      for (int h = 0; h < g.H; ++h) sum += root[h];
+      out2[t] = (t == 0 ? sum : -sum) / g.H;
+    }
+  }
+
   // edge-indexed [N-1][H] device array -> the reference's dense TreeStrategy [N][H][A] on the host (small games: tests)
   void dense(const double* edge_dev, double* out) {
     const int H = g.H, A = g.A;
@@ -894,8 +1146,34 @@ int rbl_stream_get(rbl_stream* s, int which, double* out) {
       case RBL_GET_LAST: s->impl.dense(s->impl.d_sigma.p, out); break;
       case RBL_GET_REGRETS: s->impl.dense(s->impl.d_regrets.p, out); break;
       case RBL_GET_SUM: s->impl.dense(s->impl.d_sums.p, out); break;
+      case RBL_GET_SAMPLED:
+        if (!s->impl.n_samples) throw std::runtime_error("rbl_stream_get: no sampled repeat yet");
+        s->impl.dense(s->impl.d_samp.p, out);
+        break;
+      case RBL_GET_FINAL: s->impl.sampled_final(); s->impl.dense(s->impl.d_final.p, out); break;
       default: throw std::runtime_error("rbl_stream_get: bad selector");
     }
+  });
+}
+int rbl_stream_sampled_reset(rbl_stream* s) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    s->impl.sampled_reset();
+  });
+}
+int rbl_stream_sampled_add(rbl_stream* s, rbl_engine* e, int seed) {
+  return stream_guard([&] {
+    if (!s || !e) throw std::runtime_error("null stream solver or engine");
+    s->impl.sampled_add(rbl::engine_impl(e), seed);
+  });
+}
+int rbl_stream_sampled_eval(rbl_stream* s, double exploitability[2], double ev_of_full[2]) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    s->impl.sampled_final();
+    s->impl.exploitability(s->impl.d_final.p, exploitability);
+    s->impl.average();
+    s->impl.ev2(s->impl.d_avg.p, s->impl.d_final.p, ev_of_full);
   });
 }
 }

@@ -18,6 +18,11 @@ What it reproduces:
     strategies (compute_immediate_regrets, subgame_solving.cc:984-1050 -> rbl_immediate_regrets), CFR runs only, as in
     the reference (:354-357).
 Not reproduced: strategy dumps, oracle-net mode.
+
+`--stream`: the same tool with every full-tree array edge-indexed in HBM (rbl_stream_*, eval_stream.hip) instead of dense
+[N][H][A] host arrays -- the only way to run it at 2 dice x 6 faces (33.5 M nodes: 241 GB dense, 9.7 GB edge-indexed per
+strategy).  CFR only, no --root_only, no regret reports; the numbers are bit-identical to the dense path where both run
+(tests/test_eval_parity.py::test_stream_sampled_repeats_bit_exact).
 """
 import argparse
 import json
@@ -49,6 +54,66 @@ def reach_of_actor(tree, strategy, H):
     return reach[players, np.arange(N)]  # [N][H]
 
 
+def load_net(eng, path):
+    if path == "zero":
+        eng.set_net_zero()
+        return
+    from rebel_amd.models import mlp_weights_from_state_dict
+    import torch
+    if path.endswith(".npz"):
+        sd = {k: torch.from_numpy(v) for k, v in np.load(path).items()}
+    else:
+        sd = torch.load(path, map_location="cpu")
+    eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
+
+
+def main_stream(a):
+    import time
+
+    from rebel_amd import capi
+
+    assert a.cfr and not a.root_only, "--stream: CFR solvers only, no --root_only"
+    d, f = a.num_dice, a.num_faces
+    base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear, use_cfr=True, optimistic=a.optimistic)
+    t0 = time.perf_counter()
+    s = capi.StreamSolver(d, f, capi.make_params(max_depth=100000, **base), device=a.device)
+    print(f"num_dice={d} num_faces={f}")
+    print(f"Tree of depth {s.A} has {s.nodes} nodes")
+    print("##############################################\n##### Solving the game for the full tree #####\n"
+          "##############################################")
+    for it in range(a.subgame_iters):
+        s.step(1)
+        if ((it + 1) & it) == 0 or it + 1 == a.subgame_iters:
+            ex = s.exploitability()
+            print("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e" % (it + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2), flush=True)
+    print(f"Full FP exploitability: {(ex[0] + ex[1]) / 2:.6f} ({ex[0]:.6f},{ex[1]:.6f})")
+    t_full = time.perf_counter() - t0
+    results = [("net", a.net), ("full_tree", "%.6f" % ((ex[0] + ex[1]) / 2))]
+    results_ev = [("net", a.net), ("full_tree", "%.6f" % 0.0)]  # compute_ev2 of a strategy against itself: (x - x) / 2
+    t_rep = 0.0
+    if a.net:
+        assert a.mdp_depth > 0, "--mdp_depth is required with --net"
+        print("##############################################\n##### Recursive solving                      #\n"
+              "##############################################")
+        eng = capi.Engine(d, f, capi.make_params(max_depth=a.mdp_depth, **base), max_lanes=a.max_lanes, device=a.device)
+        load_net(eng, a.net)
+        t1 = time.perf_counter()
+        for sid in range(max(a.num_repeats, 0)):
+            s.sampled_add(eng, sid)
+            if ((sid + 1) & sid) == 0 or sid + 1 == a.num_repeats:
+                ex, ev = s.sampled_eval()
+                print("%5d: %.6f (%.6f,%.6f)\tEV of full: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1],
+                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1]), flush=True)
+                results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
+                results_ev.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
+        t_rep = time.perf_counter() - t1
+    for name, val in results[1:]:
+        print(f" {name} {val}")
+    print("XXX " + json.dumps(dict(results), separators=(", ", ":")))
+    print("YYY " + json.dumps(dict(results_ev), separators=(", ", ":")))
+    print(f"# stream: full-tree solve {t_full:.1f} s, {max(a.num_repeats, 0)} repeats {t_rep:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num_dice", type=int, default=1)
@@ -66,7 +131,10 @@ def main():
     ap.add_argument("--num_threads", type=int, default=10)  # accepted for command-line compatibility; lanes replace threads
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--max_lanes", type=int, default=4096)
+    ap.add_argument("--stream", action="store_true")
     a = ap.parse_args()
+    if a.stream:
+        return main_stream(a)
 
     from rebel_amd import capi
 
@@ -98,16 +166,7 @@ def main():
         print("##############################################\n##### Recursive solving                      #\n"
               "##############################################")
         eng = capi.Engine(d, f, capi.make_params(max_depth=a.mdp_depth, **base), max_lanes=a.max_lanes, device=a.device)
-        if a.net == "zero":
-            eng.set_net_zero()
-        else:
-            from rebel_amd.models import mlp_weights_from_state_dict
-            import torch
-            if a.net.endswith(".npz"):
-                sd = {k: torch.from_numpy(v) for k, v in np.load(a.net).items()}
-            else:
-                sd = torch.load(a.net, map_location="cpu")
-            eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
+        load_net(eng, a.net)
         summed = reach_sum = None
         strategy_list = []
 
@@ -128,7 +187,7 @@ def main():
             if a.cfr:
                 strategy_list.append(s64.astype(np.float32).astype(np.float64))  # tensor_to_tree_strategy of a float tensor
             s = s64.astype(np.float32)
-            w = reach_of_actor(tree, s.astype(np.float64), H).astype(np.float32)[:, :, None]
+            w = reach_of_actor(tree, s64, H).astype(np.float32)[:, :, None]  # from the fp64 strategy, then rounded (:143-152)
             summed = s * w if summed is None else summed + s * w
             reach_sum = w if reach_sum is None else reach_sum + w
             if ((sid + 1) & sid) == 0 or sid + 1 == a.num_repeats:

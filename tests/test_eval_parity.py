@@ -188,6 +188,67 @@ def test_stream_solver_bit_exact(d, f, iters, variant, port):
         assert np.array_equal(s.get(ours), o.get(theirs)), ours
 
 
+@pytest.mark.parametrize("d,f,iters,depth,repeats", [(1, 4, 32, 2, 3), (1, 5, 17, 1, 2), (2, 2, 24, 3, 2), (1, 6, 20, 2, 2)])
+def test_stream_sampled_repeats_bit_exact(d, f, iters, depth, repeats):
+    """rbl_stream_sampled_*: the tool's "Recursive solving" section on edge-indexed device arrays.  Every repeat equals
+    rbl_strategy_recursive_sampled (itself pinned to the oracle in test_recursive_parity.py), the float32 reach-weighted
+    mean equals the reference's tensor arithmetic (recursive_eval.cc:136-160, 343-353) restated in numpy, exploitability and
+    compute_ev2 equal the dense kernels' -- all bit for bit."""
+    import importlib.util
+    import os
+
+    from rebel_amd import capi
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("recursive_eval_tool", os.path.join(root, "scripts", "recursive_eval.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+
+    base = dict(num_iters=iters, use_cfr=True, linear_update=True)
+    s = capi.StreamSolver(d, f, capi.make_params(max_depth=100000, **base))
+    s.step(iters)
+    full = s.get(capi.GET_AVERAGE)
+    eng = capi.Engine(d, f, capi.make_params(max_depth=depth, **base), max_lanes=64)
+    eng.set_net_zero()
+    tree = capi.unroll_tree(d, f, -1, 0, 1000000)
+    summed = reach = None
+    for seed in range(repeats):
+        s.sampled_add(eng, seed)
+        want = eng.strategy_recursive_sampled(seed, False)
+        assert np.array_equal(s.get(capi.GET_SAMPLED), want), seed
+        w = tool.reach_of_actor(tree, want, s.H).astype(np.float32)[:, :, None]
+        s32 = want.astype(np.float32)
+        summed = s32 * w if summed is None else summed + s32 * w
+        reach = w if reach is None else reach + w
+        final = (summed / (reach + np.float32(1e-6))).astype(np.float64)
+        assert np.array_equal(s.get(capi.GET_FINAL), final), seed
+    ex, ev = s.sampled_eval()
+    assert np.array_equal(ex, capi.exploitability2(d, f, final))
+    assert np.array_equal(ev, capi.ev2(d, f, full, final))
+    s.sampled_reset()
+    s.sampled_add(eng, 1)
+    assert np.array_equal(s.get(capi.GET_SAMPLED), eng.strategy_recursive_sampled(1, False))
+
+
+def test_recursive_eval_tool_stream_mode_equals_dense_mode():
+    """scripts/recursive_eval.py --stream (every full-tree array edge-indexed on the device) prints the same trace, XXX and
+    YYY lines as the dense mode, which is pinned to the reference binary below."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--num_dice", "1", "--num_faces", "4", "--subgame_iters", "32", "--mdp_depth", "2", "--num_repeats", "4", "--net", "zero",
+            "--cfr"]
+    outs = []
+    for extra in ([], ["--stream"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py")] + args + extra, cwd=root,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith(("Iter=", "XXX ", "YYY ", "Full FP")) or l[:5].strip().isdigit() and l[5:6] == ":"])
+    assert outs[0] == outs[1] and len(outs[0]) >= 6 + 1 + 3 + 2, outs
+
+
 def test_recursive_eval_tool_vs_reference_binary():
     """scripts/recursive_eval.py against the UNMODIFIED reference tool (oracle/_ref/recursive_eval = recursive_eval.cc built by
     oracle/Makefile; golden stdout in tests/golden/recursive_eval_1d4f.json, made by make_recursive_eval_golden.py): the
