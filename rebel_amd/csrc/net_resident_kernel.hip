@@ -116,12 +116,12 @@ __device__ __forceinline__ void lds_barrier() {
 // has ~200 cycles of matrix work in front of it.
 // NRES k-steps with weights in wh / wl, then NTAIL more from th / tl (fragments requested from L2 just before the call:
 // they land while the resident k-steps are being multiplied); NT1 = max(NTAIL, 1) is only the array bound
-template <int NRES, int NTAIL, int NT1>
+template <int NRES, int NTAIL, int NT1, int PF>
 __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW],
                                               const Frag (&th)[NT1][kOTW], const Frag (&tl)[NT1][kOTW],
                                               const f32x4* __restrict__ X, int lane, f32x4 (&acc)[kOTW][kRT]) {
   constexpr int NKS = NRES + NTAIL;
-  constexpr int NS = NKS * kRT, PF = 2;
+  constexpr int NS = NKS * kRT;
   Frag xb[PF + 1][2];
 #pragma unroll
   for (int s = 0; s < PF && s < NS; ++s) {
@@ -137,6 +137,13 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
       xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef RBL_SPLIT_KS
+    if (rt == 0 && ks > 0 && ks % RBL_SPLIT_KS == 0) {
+      int z = lane;
+      asm volatile("" : "+v"(z));
+      if (z == 0x7fffffff) asm volatile("s_nop 0");
+    }
+#endif
     const bool tail = ks >= NRES;
     const int kr = tail ? 0 : ks, kt = tail ? ks - NRES : 0;
 #pragma unroll
@@ -152,11 +159,66 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
   }
 }
 
-// K0C: 32-wide k chunks of the input layer (1 for n_in <= 32: its weights stay resident); LN: LayerNorm on / off
-template <int K0C, bool LN>
+// The hidden layer when not all of its weights are resident (more than one input chunk).  k-steps are multiplied in the order
+// [NEARLY streamed, NRES resident, NTAIL - NEARLY streamed]: the first streamed ones were requested before the layer-0 epilogue
+// and are there; once they have been used, `fetch_late` requests the remaining ones INTO THE SAME REGISTERS, and the resident
+// k-steps (>= 16 steps of matrix work per wave) cover that round trip.  Streamed weights so never hold more than NEARLY k-steps
+// of registers (2 x 16 VGPRs instead of up to 64: what hipcc could not fit and spilled from the resident set).
+template <int NRES, int NTAIL, int NEARLY, int NE1, int PF, class FetchLate>
+__device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW], Frag (&th)[NE1][kOTW],
+                                            Frag (&tl)[NE1][kOTW], const f32x4* __restrict__ X, int lane,
+                                            f32x4 (&acc)[kOTW][kRT], FetchLate&& fetch_late) {
+  static_assert(NTAIL - NEARLY <= NEARLY, "late k-steps reuse the early ones' registers");
+  constexpr int NKS = NRES + NTAIL, NS = NKS * kRT;
+  // position in the multiplication order -> k-step of the X image
+  auto ks_of = [](int p) { return p < NEARLY ? NRES + p : (p < NEARLY + NRES ? p - NEARLY : p); };
+  Frag xb[PF + 1][2];
+#pragma unroll
+  for (int s = 0; s < PF && s < NS; ++s) {
+    const int k = ks_of(s / kRT);
+    xb[s][0].v = X[((k * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
+    xb[s][1].v = X[((k * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int p = s / kRT, rt = s % kRT, slot = s % (PF + 1);
+    if (s + PF < NS) {
+      const int n = s + PF, nslot = n % (PF + 1), k = ks_of(n / kRT);
+      xb[nslot][0].v = X[((k * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
+      xb[nslot][1].v = X[((k * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool res = p >= NEARLY && p < NEARLY + NRES;
+    const int kr = res ? p - NEARLY : 0;
+    const int kt = res ? 0 : (p < NEARLY ? p : p - NRES - NEARLY);  // register slot of a streamed k-step
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(res ? wl[kr][ot].h : tl[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][1].h, acc[ot][rt]);
+#pragma unroll
+    for (int ot = 0; ot < kOTW; ++ot)
+      acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (NTAIL > NEARLY && s == NEARLY * kRT - 1) {
+      fetch_late();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// K0C: 32-wide k chunks of the input layer (1 for n_in <= 32: its weights stay resident); LN: LayerNorm on / off;
+// NOTV: 1 = one output tile (16 outputs), multiplied straight from the last epilogue's registers; 3 = two or three tiles, all
+// from registers (the third is skipped at run time when m.out_tiles == 2); 4 = four tiles: the first from registers, the rest
+// through the X image.  (The X-image loop is compiled into variant 4 only: next to the prefetched layer-0 weights of the next
+// group its fragments pushed the K0C = 4 kernel 40 VGPRs over budget, and hipcc spilled RESIDENT hidden weights for it --
+// reloaded from scratch, with a full vmcnt wait, inside the hidden GEMM of every group.)
+template <int K0C, bool LN, int NOTV>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups,
                                                                     const long long* __restrict__ range) {
+  constexpr int NOT = NOTV == 4 ? 1 : NOTV;  // tiles multiplied from registers
   const float* q_stat = m.q_stat;
   if (range) {  // device-side row range (resident self-play: the host never learns the row counts of an epoch)
     const long long r0 = range[0], r1 = range[1];
@@ -181,18 +243,37 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   long long* dbg = m.dbg && blockIdx.x < 1024 ? m.dbg + (size_t)blockIdx.x * 16 : nullptr;
   long long* const dbg_end = dbg;
   int dbg_k = 0;
+#ifdef RBL_NO_STAMPS
+#define RBL_NSTAMP() __builtin_amdgcn_sched_barrier(0)
+#else
 #define RBL_NSTAMP()                                              \
   do {                                                            \
+    __builtin_amdgcn_sched_barrier(0);                            \
     if (dbg && tid == 0) dbg[dbg_k] = (long long)clock64();       \
     ++dbg_k;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                            \
   } while (0)
+#endif
 
   // ---------------------------------------------------------------- this wave's weights, resident for the whole launch
   const f32x4* blob = reinterpret_cast<const f32x4*>(m.tape);
   // With more than one input k chunk (n_in > 32: 2dx3f, 2dx6f) the per-group state no longer fits next to all 8 hidden
   // k-steps (hipcc spilled 4-6 weight fragments and reloaded them from scratch every group); the last kTail k-steps are
   // then streamed from L2 per group instead, requested right before the hidden GEMM and used at its end.
-  constexpr int kTail = K0C == 1 ? 0 : (K0C == 2 ? 1 : (K0C == 3 ? 3 : 4)), kRes = kKS - kTail, kT1 = kTail > 0 ? kTail : 1;
+#ifndef RBL_KTAIL4
+#define RBL_KTAIL4 4
+#endif
+#ifndef RBL_KTAIL3
+#define RBL_KTAIL3 3
+#endif
+#ifndef RBL_KEARLY
+#define RBL_KEARLY 2
+#endif
+  constexpr int kTail = K0C == 1 ? 0 : (K0C == 2 ? 1 : (K0C == 3 ? RBL_KTAIL3 : RBL_KTAIL4)), kRes = kKS - kTail,
+                kEarly = kTail < RBL_KEARLY ? kTail : RBL_KEARLY, kE1 = kEarly > 0 ? kEarly : 1;
+  // B fragments requested this many steps ahead of their MFMAs; 1 with three or four input chunks (a third ring slot = 8
+  // more VGPRs made hipcc spill 36-bytes' worth of resident weights at K0C = 3)
+  constexpr int kPF = K0C >= 3 ? 1 : 2;
   Frag w1h[kRes][kOTW], w1l[kRes][kOTW];
   const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
   {
@@ -264,10 +345,16 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // variance (one float per row and wave).  The first barrier doubles as "everybody is done reading the old X".
   auto epilogue_regs = [&](auto last_tag, float inv_s, const float* pl) {
     constexpr bool kLast = decltype(last_tag)::value;  // feeds the output layer: tile 0 straight from registers
-    Frag woh, wol;  // output layer, tile 0, k-step `wave`: 2 KB from L2 per wave and group, requested here, used at the end
+    // output layer, k-step `wave` of the first NOT tiles: 2 KB per tile from L2 per wave and group, requested here, used at
+    // the end
+    Frag woh[NOT], wol[NOT];
     if constexpr (kLast) {
-      woh.v = reinterpret_cast<const f32x4*>(m.wo)[(wave * 2 + 0) * 64 + lane];
-      wol.v = reinterpret_cast<const f32x4*>(m.wo)[(wave * 2 + 1) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < NOT; ++t) {
+        const int tt = t < m.out_tiles ? t : 0;
+        woh[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 0) * 64 + lane];
+        wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
+      }
     }
     f32x4 d[kOTW][kRT];
 #pragma unroll
@@ -337,15 +424,22 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       Frag fh, fl;
       fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};
       fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
-      if (!kLast || m.out_tiles > 1) {
+      if (!kLast || NOTV == 4) {
         X[((wave * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
         X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
       }
       if constexpr (kLast) {  // this wave's 32-wide k slice of the output layer, summed over the waves below
-        f32x4 o = RBL_MFMA(wol.h, fh.h, (f32x4{0.f, 0.f, 0.f, 0.f}));
-        o = RBL_MFMA(woh.h, fl.h, o);
-        o = RBL_MFMA(woh.h, fh.h, o);
-        P[(wave * kRT + rt) * 64 + lane] = o;
+#pragma unroll
+        for (int t = 0; t < NOT; ++t) {
+          if (t > 0 && t >= m.out_tiles) break;
+          f32x4 o = RBL_MFMA(wol[t].h, fh.h, (f32x4{0.f, 0.f, 0.f, 0.f}));
+          o = RBL_MFMA(woh[t].h, fl.h, o);
+          o = RBL_MFMA(woh[t].h, fh.h, o);
+          // partials of tile 0 have their own buffer; those of tiles 1, 2 take over the X image, which nobody reads between
+          // the first barrier of this epilogue (every wave is past the hidden GEMM) and the next group's staging
+          f32x4* pt = t == 0 ? P : X + (size_t)(t - 1) * kWaves * kRT * 64;
+          pt[(wave * kRT + rt) * 64 + lane] = o;
+        }
       }
     }
     lds_barrier();
@@ -398,62 +492,79 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
     // -------------------------------------------------------------- layer 0
     zero_acc();
-    gemm_resident<K0C, 0, K0C>(th, tl, th, tl, X, lane, acc);
+    gemm_resident<K0C, 0, K0C, kPF>(th, tl, th, tl, X, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
+    // The streamed k-steps of the hidden layer take over registers of the layer-0 weights (dead from here on): the first kEarly
+    // of them are requested BEFORE the layer-0 epilogue, whose ~6 k cycles cover the L2 round trips; the rest is requested
+    // inside the hidden GEMM into the same registers (gemm_hidden).  History: all requested after the epilogue, the hidden GEMM
+    // waited for them (8.8 k cycles instead of 3.8 k at 2 dice x 6 faces).
+    Frag t7h[kE1][kOTW], t7l[kE1][kOTW];
+    const f32x4* wt = w1 + (size_t)kRes * kOTW * 2 * 64;
+    asm volatile("" : "+s"(wt));  // a fresh load every group
+    auto fetch_tail = [&](auto lo_tag, auto hi_tag, auto slot0_tag) {  // streamed k-steps [lo, hi) -> slots slot0 ..
+#pragma unroll
+      for (int ks = decltype(lo_tag)::value; ks < decltype(hi_tag)::value; ++ks)
+#pragma unroll
+        for (int ot = 0; ot < kOTW; ++ot) {
+          const int sl = ks - decltype(lo_tag)::value + decltype(slot0_tag)::value;
+          t7h[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+          t7l[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using IE = std::integral_constant<int, kEarly>;
+    using IT = std::integral_constant<int, kTail>;
+    fetch_tail(I0{}, IE{}, I0{});
     RBL_NSTAMP();  // 3
     epilogue_regs(std::false_type{}, m.inv_scale[0], prm);
     RBL_NSTAMP();  // 4: L0 epilogue
 
     // -------------------------------------------------------------- hidden layer, weights from registers
     zero_acc();
-    {
-      Frag t7h[kT1][kOTW], t7l[kT1][kOTW];
-      if constexpr (kTail > 0) {
-        const f32x4* wt = w1 + (size_t)kRes * kOTW * 2 * 64;
-        asm volatile("" : "+s"(wt));  // a fresh load every group
-#pragma unroll
-        for (int ks = 0; ks < kTail; ++ks)
-#pragma unroll
-          for (int ot = 0; ot < kOTW; ++ot) {
-            t7h[ks][ot].v = wt[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-            t7l[ks][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
-          }
-      }
-      gemm_resident<kRes, kTail, kT1>(w1h, w1l, t7h, t7l, X, lane, acc);
-    }
+    if constexpr (kTail == 0)
+      gemm_resident<kRes, 0, 1, kPF>(w1h, w1l, t7h, t7l, X, lane, acc);
+    else
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(IE{}, IT{}, I0{}); });
     RBL_NSTAMP();  // 5: hidden gemm
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
     RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
+#ifndef RBL_W0_LATE
     if (grp + (int)gridDim.x < n_groups) fetch_w0();
+#endif
 
-    // -------------------------------------------------------------- output tile 0: sum the 8 k slices, waves 0-3
-    if (wave < kRT) {
-      const int rt = wave;
-      f32x4 o = P[(0 * kRT + rt) * 64 + lane];
+    // -------------------------------------------------------------- register tiles: sum the 8 k slices of (tile, row tile)
+    {
+      const int n_reg = m.out_tiles < NOT ? m.out_tiles : NOT;
+      for (int p = wave; p < n_reg * kRT; p += kWaves) {
+        const int t = p >> 2, rt = p & 3;
+        const f32x4* pt = t == 0 ? P : X + (size_t)(t - 1) * kWaves * kRT * 64;
+        f32x4 o = pt[(0 * kRT + rt) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < kWaves; ++w) o += P[(w * kRT + rt) * 64 + lane];
-      // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
-      int r_in = rt * 16 + j, col = 4 * g;
-      const int n_out = m.n_out;
-      asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
-      const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
-      float* og = out + row0 * n_out;
-      const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
-      if (r_in < rows_here) {
-        if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
-          f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
-          if (col + 1 < n_out) p2[0] = f32x2{r4[0], r4[1]};
-          if (col + 3 < n_out) p2[1] = f32x2{r4[2], r4[3]};
-        } else {
+        for (int w = 1; w < kWaves; ++w) o += pt[(w * kRT + rt) * 64 + lane];
+        // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
+        int r_in = rt * 16 + j, col = t * 16 + 4 * g;
+        const int n_out = m.n_out;
+        asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
+        const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
+        float* og = out + row0 * n_out;
+        const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
+        if (r_in < rows_here) {
+          if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
+            f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
+            if (col + 1 < n_out) p2[0] = f32x2{r4[0], r4[1]};
+            if (col + 3 < n_out) p2[1] = f32x2{r4[2], r4[3]};
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+            for (int r = 0; r < 4; ++r)
+              if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+          }
         }
       }
     }
     // -------------------------------------------------------------- further output tiles (n_out > 16): from the X image
-    for (int ot = 1; ot < m.out_tiles; ++ot) {
+    if constexpr (NOTV == 4)
+    for (int ot = NOT; ot < m.out_tiles; ++ot) {
       const int rt = wave & 3, kh = wave >> 2;
       const f32x4* wo = reinterpret_cast<const f32x4*>(m.wo) + (size_t)ot * kWoF4;
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
@@ -489,8 +600,11 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         }
       }
     }
-    if (m.out_tiles > 1) lds_barrier();  // X and P change hands
+    if (NOTV > 1 && m.out_tiles > 1) lds_barrier();  // X and P change hands
     RBL_NSTAMP();  // 8: output layer
+#ifdef RBL_W0_LATE
+    if (grp + (int)gridDim.x < n_groups) fetch_w0();
+#endif
     dbg = nullptr;  // stamps describe the first group of each workgroup
   }
   if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
@@ -516,15 +630,22 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   const int cus = dev < 64 ? n_cu[dev] : 256;
   const int n_groups = (int)((rows + kRows - 1) / kRows);
   const int grid = n_groups < cus ? n_groups : cus;
-#define RBL_RES(K0C_)                                                                                              \
-  do {                                                                                                             \
-    if (m.use_ln)                                                                                                  \
-      hipLaunchKernelGGL((mlp_resident_kernel<K0C_, true>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries,  \
-                         rows, out, n_groups, range);                                                              \
-    else                                                                                                           \
-      hipLaunchKernelGGL((mlp_resident_kernel<K0C_, false>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
-                         rows, out, n_groups, range);                                                              \
+#define RBL_RES2(K0C_, LN_, NOT_)                                                                                    \
+  hipLaunchKernelGGL((mlp_resident_kernel<K0C_, LN_, NOT_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows, \
+                     out, n_groups, range)
+#define RBL_RES(K0C_)                                    \
+  do {                                                   \
+    if (m.use_ln) {                                      \
+      if (variant == 1) RBL_RES2(K0C_, true, 1);         \
+      else if (variant == 3) RBL_RES2(K0C_, true, 3);    \
+      else RBL_RES2(K0C_, true, 4);                      \
+    } else {                                             \
+      if (variant == 1) RBL_RES2(K0C_, false, 1);        \
+      else if (variant == 3) RBL_RES2(K0C_, false, 3);   \
+      else RBL_RES2(K0C_, false, 4);                     \
+    }                                                    \
   } while (0)
+  const int variant = m.out_tiles == 1 ? 1 : (m.out_tiles <= 3 ? 3 : 4);
   if (m.out_tiles < 1 || m.out_tiles > 4) throw std::runtime_error("launch_mlp_resident: unsupported n_out");
   switch (m.l0_chunks) {
     case 1: RBL_RES(1); break;
@@ -533,6 +654,7 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
     default: RBL_RES(4); break;
   }
 #undef RBL_RES
+#undef RBL_RES2
 }
 
 }  // namespace rbl
