@@ -43,6 +43,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));  // dword-aligned 16-byte access
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -274,6 +275,10 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // B fragments requested this many steps ahead of their MFMAs; 1 with three or four input chunks (a third ring slot = 8
   // more VGPRs made hipcc spill 36-bytes' worth of resident weights at K0C = 3)
   constexpr int kPF = K0C >= 3 ? 1 : 2;
+#ifndef RBL_W0_LATE_MIN
+#define RBL_W0_LATE_MIN 3
+#endif
+  constexpr bool kW0Late = K0C >= RBL_W0_LATE_MIN;
   Frag w1h[kRes][kOTW], w1l[kRes][kOTW];
   const f32x4* w1 = reinterpret_cast<const f32x4*>(m.wh) + (size_t)wave * kKS * kOTW * 2 * 64;
   {
@@ -319,14 +324,23 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       }
       return;
     }
+    // canonical rows (n_in floats, 4-byte aligned): a thread's four consecutive inputs are ONE dword-aligned 16-byte load
+    // when they all exist (gfx950 global loads need dword alignment only); the piece that straddles the end of the row is
+    // read element by element.  (16 predicated dword loads per thread at n_in = 99 were ~2 k cycles of a 64-row group.)
     const float* q = queries + (ok ? row : 0) * n_in;
 #pragma unroll
-    for (int ks = 0; ks < K0C; ++ks)
+    for (int ks = 0; ks < K0C; ++ks) {
+      const int k0 = 32 * ks + 8 * g + 4 * (wave & 1);
+      if (32 * ks + 32 <= n_in || k0 + 4 <= n_in) {  // first clause: uniform, whole chunk inside the row
+        f32x4u v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4u*>(q + k0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = 32 * ks + 8 * g + 4 * (wave & 1) + e;
-        qn[ks][e] = (ok && k < n_in) ? q[k] : 0.f;
+        for (int e = 0; e < 4; ++e) qn[ks][e] = v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qn[ks][e] = (ok && k0 + e < n_in) ? q[k0 + e] : 0.f;
       }
+    }
   };
 
   f32x4 acc[kOTW][kRT];
@@ -529,9 +543,10 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
     RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
-#ifndef RBL_W0_LATE
-    if (grp + (int)gridDim.x < n_groups) fetch_w0();
-#endif
+    // with three or four input chunks (48 / 64 KB per CU) the request goes out AFTER the output stores below: VMEM issues in
+    // order, and behind 64 KB of weight loads the stores (and the waves issuing them) waited ~2 k cycles
+    if constexpr (!kW0Late)
+      if (grp + (int)gridDim.x < n_groups) fetch_w0();
 
     // -------------------------------------------------------------- register tiles: sum the 8 k slices of (tile, row tile)
     {
@@ -602,9 +617,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     }
     if (NOTV > 1 && m.out_tiles > 1) lds_barrier();  // X and P change hands
     RBL_NSTAMP();  // 8: output layer
-#ifdef RBL_W0_LATE
-    if (grp + (int)gridDim.x < n_groups) fetch_w0();
-#endif
+    if constexpr (kW0Late)
+      if (grp + (int)gridDim.x < n_groups) fetch_w0();
     dbg = nullptr;  // stamps describe the first group of each workgroup
   }
   if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
