@@ -57,7 +57,8 @@ class KernelStats(C.Structure):
 
 
 CFR_KERNEL_NAMES = {0: "cfr_step_kernel (generic)", 1: "cfr_rows_kernel (one thread per tree row)",
-                    2: "cfr_wave_kernel (one wavefront per lane)", 3: "cfr_rows_kernel<GS> (global state, 2dx6f)"}
+                    2: "cfr_wave_kernel (one wavefront per lane)", 3: "cfr_rows_kernel<GS> (global state, 2dx6f)",
+                    4: "cfr_flat_kernel (element-parallel, sigma in LDS, 2dx6f)"}
 NET_KERNEL_NAMES = {0: "none", 3: "mlp_fsplit_forward_kernel (feature split)",
                     5: "mlp_resident_kernel (f16x2-split MFMA, register-resident weights)",
                     6: "mlp_pipe_kernel (f16x2-split MFMA 32x32x16, software-pipelined)"}

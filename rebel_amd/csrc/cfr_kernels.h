@@ -30,6 +30,7 @@ struct CfrArgs {
   const int* terms;
   const int* irank;     // node -> index of its reach row (root / nodes with children), -1 otherwise (cfr_rows_kernel)
   const int* leaf_row;  // node -> net row within the lane for pseudo-leaves, -1 otherwise (cfr_rows_kernel)
+  const int* vrow;      // node -> rank among the nodes that are not pseudo-leaves, -1 for those (cfr_rows_kernel<GS>)
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
   const int8_t* wave_tabs;  // cfr_wave_kernel: per shape parent | act | cb | ce | depth | irank (N bytes each) | leaf nodes (L) |
   const int* wave_tab_off;  //                  terminal nodes (T) as one 4-byte aligned blob; byte offset of each shape's blob
@@ -108,8 +109,12 @@ bool cfr_wave_supported(int H, int A, int dice, int faces, int max_EH, int max_L
 bool launch_cfr_wave(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream);
 // the same kernel for lanes whose state does not fit LDS (2 dice x 6 faces): node values and reach rows in LDS, sigma /
 // regrets in place in global memory, 256 threads, one lane per CU
-size_t cfr_rows_global_lds_bytes(int N, int NI, int H, int faces);
+size_t cfr_rows_global_lds_bytes(int N, int NI, int H, int L, int faces);
 bool cfr_rows_global_supported(int H, int A, int dice, int faces);
 bool launch_cfr_rows_global(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream);
+// cfr_flat_kernel.hip: the same lanes with element-parallel passes and sigma resident in LDS (the default at 2 dice x 6 faces)
+size_t cfr_flat_lds_bytes(int N, int NI, int H, int L, int T, int faces);
+bool cfr_flat_supported(int H, int A, int dice, int faces);
+bool launch_cfr_flat(const CfrArgs& a, int B, size_t lds_bytes, int threads, hipStream_t stream);
 
 }  // namespace rbl

@@ -178,7 +178,7 @@ class Engine {
   hipStream_t part_stream(int part) const { return part == 0 ? stream_ : part == 1 ? stream2_ : stream_x_[part - 2]; }
 
   DevBuf<ShapeDev> d_shapes_;
-  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_;
+  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_, d_vrow_;
   DevBuf<int8_t> d_matches_, d_wave_tabs_;
   DevBuf<int> d_wave_tab_off_;
   DevBuf<int> d_shape_epar_;
@@ -219,11 +219,23 @@ class Engine {
   size_t wave_lds_bytes_ = 0;
   bool rows_global_ok_ = false;  // big games: row kernel with sigma / regrets in place in global memory
   size_t rows_global_lds_ = 0;
+  int flat_threads_ = 1024;
+  bool flat_ok_ = false;         // ... served by cfr_flat_kernel (element-parallel, sigma in LDS) instead
+  size_t gs_lds_bytes(const ShapeDev& s) const {
+    return flat_ok_ ? cfr_flat_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces) : cfr_rows_global_lds_bytes(s.N, s.NI, g_.H, s.L, g_.faces);
+  }
   // ... launched per segment of the part's lanes sorted by tree size, each with the LDS request of ITS largest tree: one
   // root-sized lane per CU (124 KB), but two to four of the smaller trees that make up most of a self-play batch
   bool use_order_ = false;
   DevBuf<int> d_lane_order_;
   size_t seg_lds_[4][kSpSegs] = {};
+  int seg_threads_[4][kSpSegs] = {};  // cfr_flat_kernel: workgroup size of a segment, by its largest tree
+  // a lane's passes are (node, hand) items: small trees on a 1024-thread workgroup leave most of it idle and, at 16 waves,
+  // have the CU to themselves; sized to ~12 items per thread instead, eight of them share a CU
+  int flat_threads_for(int N) const {
+    const int want = N > 200 ? 1024 : (N > 80 ? 512 : (N > 30 ? 256 : 128));
+    return std::min(want, flat_threads_);
+  }
   void set_segments(const int (*seg_shape)[kSpSegs]);  // LDS request of each launch segment from its head lane's shape
   size_t part_rows_lds_[4] = {0, 0, 0, 0};  // per part: LDS of the largest tree among its lanes (set by reset)
   int part_rows_block_[4] = {128, 128, 128, 128};

@@ -105,6 +105,7 @@ void Engine::construct() {
   d_terms_.upload(padded(tabs_.terms), stream_);
   d_irank_.upload(padded(tabs_.irank), stream_);
   d_leaf_row_.upload(padded(tabs_.leaf_row), stream_);
+  d_vrow_.upload(padded(tabs_.vrow), stream_);
   {  // byte blobs of the per-shape tables in the one-wavefront kernel's LDS layout (staged with dword loads)
     std::vector<int8_t> blob;
     std::vector<int> off;
@@ -188,15 +189,24 @@ void Engine::construct() {
                cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
   }
   // big games (2 dice x 6 faces): the row kernel with the strategy arrays in place in global memory
-  rows_global_lds_ = 0;
+  // ... or, the default, the element-parallel kernel with sigma resident in LDS (cfr_flat_kernel.hip); it needs a root with
+  // children in every shape (max_depth >= 1) and 147 KB of LDS at the root of a depth-2 subgame
+  flat_ok_ = env_int("RBL_CFR_FLAT", 1) != 0 && cfr_flat_supported(g_.H, g_.A, g_.dice, g_.faces);
   for (const ShapeDev& s : tabs_.shapes)
-    rows_global_lds_ = std::max(rows_global_lds_, cfr_rows_global_lds_bytes(s.N, s.NI, g_.H, g_.faces));
+    if (tabs_.cb[s.node_off] == tabs_.ce[s.node_off] || cfr_flat_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces) > 160 * 1024)
+      flat_ok_ = false;
+  rows_global_lds_ = 0;
+  for (const ShapeDev& s : tabs_.shapes) rows_global_lds_ = std::max(rows_global_lds_, gs_lds_bytes(s));
   rows_global_ok_ = !use_lds_ && env_int("RBL_CFR_ROWS", 1) && cfr_rows_global_supported(g_.H, g_.A, g_.dice, g_.faces) &&
                     rows_global_lds_ <= 160 * 1024;
+  flat_ok_ = flat_ok_ && rows_global_ok_;
+  flat_threads_ = std::min(1024, std::max(64, env_int("RBL_CFR_FLAT_THREADS", 1024) / 64 * 64));
   use_order_ = rows_global_ok_ && env_int("RBL_GS_SORT", 1) != 0;
   if (use_order_) d_lane_order_.alloc((size_t)max_lanes_);
   for (auto& row : seg_lds_)
     for (size_t& v : row) v = rows_global_lds_;
+  for (auto& row : seg_threads_)
+    for (int& v : row) v = flat_threads_;
   rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   cfr_dbg_ = env_int("RBL_CFR_DBG", 0) != 0;
@@ -621,7 +631,8 @@ void Engine::set_segments(const int (*seg_shape)[kSpSegs]) {
       const int sid = pt < n_parts_ ? seg_shape[pt][k] : 0;
       if (sid < 0 || sid >= (int)tabs_.shapes.size()) throw std::runtime_error("engine: bad segment head shape");
       const ShapeDev& sh = tabs_.shapes[sid];
-      seg_lds_[pt][k] = cfr_rows_global_lds_bytes(sh.N, sh.NI, g_.H, g_.faces);
+      seg_lds_[pt][k] = gs_lds_bytes(sh);
+      seg_threads_[pt][k] = flat_threads_for(sh.N);
     }
 }
 
@@ -693,6 +704,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.terms = d_terms_.p;
   a.irank = d_irank_.p;
   a.leaf_row = d_leaf_row_.p;
+  a.vrow = d_vrow_.p;
   a.matches = d_matches_.p;
   a.wave_tabs = d_wave_tabs_.p;
   a.wave_tab_off = d_wave_tab_off_.p;
@@ -750,13 +762,15 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
         const int p0 = l0 + (int)((long long)cnt * k / ns), p1 = l0 + (int)((long long)cnt * (k + 1) / ns);
         if (p1 <= p0) continue;
         a.lane0 = p0;
-        launch_cfr_rows_global(a, p1 - p0, seg_lds_[part][k], st);
+        if (flat_ok_) launch_cfr_flat(a, p1 - p0, seg_lds_[part][k], seg_threads_[part][k], st);
+        else launch_cfr_rows_global(a, p1 - p0, seg_lds_[part][k], st);
       }
       a.lane_order = nullptr;
       a.lane0 = l0;
-      which = 3;
-    } else if (mode == kModeStep && rows_global_ok_ && launch_cfr_rows_global(a, cnt, rows_global_lds_, st)) {
-      which = 3;
+      which = flat_ok_ ? 4 : 3;
+    } else if (mode == kModeStep && rows_global_ok_ &&
+               (flat_ok_ ? launch_cfr_flat(a, cnt, rows_global_lds_, flat_threads_, st) : launch_cfr_rows_global(a, cnt, rows_global_lds_, st))) {
+      which = flat_ok_ ? 4 : 3;
     } else if (mode == kModeStep && rows_ok_ && launch_cfr_rows(a, cnt, part_rows_block_[part], part_rows_lds_[part], st)) {
       which = 1;
     } else {

@@ -80,6 +80,7 @@ struct ShapeDev {
 struct ShapeTables {
   std::vector<ShapeDev> shapes;  // index = root_last_bid + 1
   std::vector<int> parent, act, cb, ce, depth, leaf_row, irank, leaves, terms;
+  std::vector<int> vrow;  // node -> its rank among the nodes that are NOT pseudo-leaves (-1 for pseudo-leaves): cfr_rows_kernel<GS>
   int max_N = 0, max_L = 0, max_T = 0;
 
   // has_net=false reproduces the reference's refusal to build a truncated tree without a value net
@@ -118,6 +119,7 @@ struct ShapeTables {
         t.ce.push_back(n.ce);
         t.depth.push_back(n.depth);
         t.leaf_row.push_back(row);
+        t.vrow.push_back(row >= 0 ? -1 : i - s.L);
         t.irank.push_back((i == 0 || n.cb != n.ce) ? s.NI++ : -1);
       }
       s.nlev = lev + 1;
