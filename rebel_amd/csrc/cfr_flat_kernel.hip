@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   const int tid = threadIdx.x, NT = blockDim.x;
   const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
   const int N = shc->N, E = N - 1, L = shc->L, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
-  const int NV = N - L;
+  const int NV = N - L, T = shc->T;
   const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
   const int t = a.trav, opp = 1 - t;
 
@@ -74,9 +74,9 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   int* t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
   int* t_pack = tb + 5 * N, *t_lrow = tb + 6 * N, *t_leaf = tb + 7 * N;  // t_leaf [L]: node of net row k
   int* t_term = t_leaf + L;                                              // t_term [T]: the terminals, ascending
-  const int T = shc->T;
+  int* t_qrec = t_term + T;  // [L]: node | parent's reach row << 9 | who acted there << 17 | player to move << 18 | last bid << 19
   // t_mask [FACES][2]: bit h set when hand h shows exactly 1 / exactly 2 of the face (8-byte aligned slot after the ints)
-  unsigned long long* t_mask = reinterpret_cast<unsigned long long*>(tb + ((7 * N + L + T + 1) & ~1));
+  unsigned long long* t_mask = reinterpret_cast<unsigned long long*>(tb + ((7 * N + 2 * L + T + 1) & ~1));
 
   const size_t lane_e = (size_t)lane * a.Emax * H;
   double* g_sig = a.sigma + lane_e;
@@ -117,8 +117,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     for (int i0 = tid; i0 < EW; i0 += 12 * NT) {
       d2 v[12];
 #pragma unroll
-      for (int u = 0; u < 12; ++u)
-        if (i0 + u * NT < EW) v[u] = gs[i0 + u * NT];
+      for (int u = 0; u < 12; ++u) v[u] = gs[min(i0 + u * NT, EW - 1)];
 #pragma unroll
       for (int u = 0; u < 12; ++u)
         if (i0 + u * NT < EW) ls[i0 + u * NT] = v[u];
@@ -301,26 +300,27 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
       if (c0 == c1) continue;
-      // a pseudo-leaf's value comes from the net's rows in global memory: every child's is requested before the first is used
-      constexpr int kC = A - 1;  // most children a node can have
-      int lr[kC];
-      float lvf[kC];
-#pragma unroll
-      for (int u = 0; u < kC; ++u) {
-        lr[u] = c0 + u < c1 ? t_lrow[c0 + u] : -1;
-        lvf[u] = 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < kC; ++u)
-        if (c0 + u < c1 && lr[u] >= 0) lvf[u] = lvals[lr[u] * H + h];
+      // a pseudo-leaf's value comes from the net's rows in global memory: twelve children's are requested before the first is
+      // used (all 24 at once spilled registers to scratch: 24 k cycles for this pass at the root)
+      constexpr int kC = 12;
       double x = 0.0;
+      for (int cb = c0; cb < c1; cb += kC) {
+        int lr[kC];
+        float lvf[kC];
 #pragma unroll
-      for (int u = 0; u < kC; ++u)
-        if (c0 + u < c1) {
-          const double v = lr[u] >= 0 ? (double)(float)((double)lvf[u] * lsum[lr[u]]) : val[(-1 - lr[u]) * H + h];
-          if (mine) x += v * sig[(c0 + u - 1) * H + h];
-          else x += v;
-        }
+        for (int u = 0; u < kC; ++u) lr[u] = t_lrow[min(cb + u, c1 - 1)];
+        // unconditional loads from a row that exists (row 0 when the child is not a pseudo-leaf): a load under a condition is a
+        // branch, and loads in different basic blocks are not requested together
+#pragma unroll
+        for (int u = 0; u < kC; ++u) lvf[u] = lvals[max(lr[u], 0) * H + h];
+#pragma unroll
+        for (int u = 0; u < kC; ++u)
+          if (cb + u < c1) {
+            const double v = lr[u] >= 0 ? (double)(float)((double)lvf[u] * lsum[lr[u]]) : val[(-1 - lr[u]) * H + h];
+            if (mine) x += v * sig[(cb + u - 1) * H + h];
+            else x += v;
+          }
+      }
       val[(-1 - t_lrow[n]) * H + h] = x;
     }
     RBL_F2();  // node values
@@ -334,14 +334,13 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
         float lvf[kG];
         int lr[kG];
 #pragma unroll
-        for (int u = 0; u < kG; ++u)
-          if (i0 + u * NT < cnt) {
-            const int i = i0 + u * NT;
-            const int c = c_lo + i / H, h = i % H;
-            q[u] = g_reg[(c - 1) * H + h];
-            lr[u] = t_lrow[c];
-            lvf[u] = lr[u] >= 0 ? lvals[lr[u] * H + h] : 0.f;
-          }
+        for (int u = 0; u < kG; ++u) {  // clamped, unconditional: straight-line code
+          const int i = min(i0 + u * NT, cnt - 1);
+          const int c = c_lo + i / H, h = i % H;
+          q[u] = g_reg[(c - 1) * H + h];
+          lr[u] = t_lrow[c];
+          lvf[u] = lvals[max(lr[u], 0) * H + h];
+        }
 #pragma unroll
         for (int u = 0; u < kG; ++u)
           if (i0 + u * NT < cnt) {
@@ -383,6 +382,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       rho_t[ir * H + h] = s;
       yrow[ir * H + h] = __builtin_fma(yy, er, yy);
     }
+    RBL_F2();  // row sums
     __syncthreads();
     {
       const int cnt = (c_hi - c_lo) * H;
@@ -453,12 +453,11 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       double x[kG];
       bool own[kG];
 #pragma unroll
-      for (int u = 0; u < kG; ++u)
-        if (i0 + u * NT < cnt) {
-          const int i = i0 + u * NT;
-          own[u] = (root_player ^ pk_pdp(t_pack[1 + i / H])) == t;
-          if (own[u]) x[u] = g_sum[i];
-        }
+      for (int u = 0; u < kG; ++u) {  // clamped, unconditional: straight-line code
+        const int i = min(i0 + u * NT, cnt - 1);
+        own[u] = (root_player ^ pk_pdp(t_pack[1 + i / H])) == t;
+        x[u] = g_sum[i];
+      }
 #pragma unroll
       for (int u = 0; u < kG; ++u)
         if (i0 + u * NT < cnt) {
@@ -506,7 +505,9 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       er = __builtin_fma(-sn, y, 1.0);
       qs[4 * k + 2] = sn;
       qs[4 * k + 3] = __builtin_fma(y, er, y);
+      t_qrec[k] = n | (pr << 9) | (pm << 17) | ((root_player ^ (t_depth[n] & 1)) << 18) | (t_act[n] << 19);
     }
+    RBL_F2();  // query sums
     __syncthreads();
     // the rows themselves: one item per element, consecutive threads = consecutive floats of the exchange buffer.
     // (x + eps) / s is hipcc's f64 division sequence minus v_div_scale / v_div_fixup, the identity here
@@ -521,9 +522,8 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       for (int u = 0; u < kU; ++u) {
         const int i = min(i0 + u * NT, cnt - 1);
         const int k = i / Q, j = i - k * Q;
-        const int n = t_leaf[k];
-        const int w = t_pack[n];
-        const int pr = pk_pr(w), pm = root_player ^ pk_pdp(w);
+        const int rec = t_qrec[k];
+        const int n = rec & 511, pr = (rec >> 9) & 255, pm = (rec >> 17) & 1;
         const int jj = max(j - 2 - A, 0);
         const int wh = jj / H, h = jj % H;  // player whose reach this is
         const bool acted = wh == pm;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
         num[u] = (acted ? r * sg : r) + kEps;
         s[u] = qs[4 * k + (acted ? 0 : 2)];
         y[u] = qs[4 * k + (acted ? 1 : 3)];
-        flat[u] = j == 0 ? (float)(root_player ^ (t_depth[n] & 1)) : (j == 1 ? (float)a.next_trav : (j - 2 == t_act[n] ? 1.0f : 0.0f));
+        flat[u] = j == 0 ? (float)((rec >> 18) & 1) : (j == 1 ? (float)a.next_trav : (j - 2 == (rec >> 19) ? 1.0f : 0.0f));
         kind[u] = i0 + u * NT < cnt ? (j < 2 + A ? 0 : 1) : -1;
       }
 #pragma unroll
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 
 size_t cfr_flat_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
   const size_t d = (size_t)3 * NI * H + (size_t)(N - L) * H + (size_t)5 * L + (size_t)(N - 1) * H;  // doubles
-  const size_t b = d * 8 + (((size_t)7 * N + L + T + 1) & ~(size_t)1) * 4 + (size_t)faces * 16;
+  const size_t b = d * 8 + (((size_t)7 * N + 2 * L + T + 1) & ~(size_t)1) * 4 + (size_t)faces * 16;
   return (b + 15) & ~(size_t)15;
 }
 

@@ -14,7 +14,7 @@ e.set_net_synthetic()
 rng = np.random.default_rng(0)
 bids = np.where(np.arange(B) % 2 == 0, -1, 18).astype(np.int32)
 e.reset(bids, bids * 0, rng.dirichlet(np.ones(e.H), size=(B, 2)))
-e.multistep(9)
+e.multistep(int(os.environ.get("STEPS", "9")))
 e.sync()
 d = e.debug_stamps()[:B]
 for name, sel in (("root (N=325)", bids == -1), ("bid 18", bids == 18)):
