@@ -37,7 +37,7 @@ namespace {
 
 constexpr double kEps = 1e-80;
 constexpr int kFlatMaxThreads = 1024;
-constexpr int kG = 12;  // items per thread whose GLOBAL operands are requested together (12 x 1024 threads cover a root tree)
+constexpr int kG = 6;   // rows per thread whose GLOBAL operands are requested together (6 x 56 rows cover a root tree)
 constexpr int kU = 4;  // items whose loads are issued together: a pass is a chain of dependent LDS / memory round trips per
                        // item (table word -> operands -> store), and with 16 waves per CU only independent work inside a
                        // thread hides them (one item at a time: ~700 cycles per item, 137 k cycles per root lane)
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   double* yrow = rho1 + NI * H;  // refined reciprocals of the regret-matching row sums
   double* val = yrow + NI * H;   // values of the nodes that are not pseudo-leaves (row = -1 - t_lrow[n])
   double* lsum = val + NV * H;   // pseudo-leaf: sum of the opponent's reach
-  double* qs = lsum + L;         // query rows: [sum, reciprocal] of the acting player's reach, then of the other's
+  double* qs = lsum + ((L + 1) & ~1);  // (16-byte aligned) query rows: [sum, reciprocal] of the acting player's reach, then of the other's
   double* sig = qs + 4 * L;
   int* tb = reinterpret_cast<int*>(sig + E * H);
   int* t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
@@ -161,10 +161,28 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   }
   RBL_STAMP();  // 1: staged
 
-  // value of node c for hand h, as its parent reads it (lr = t_lrow[c])
-  auto child_val = [&](int lr, int h) {
-    if (lr >= 0) return (double)(float)((double)lvals[lr * H + h] * lsum[lr]);  // query_value_net (:257-268)
-    return val[(-1 - lr) * H + h];
+  // Geometry of the elementwise passes: a thread owns one PAIR of hands (16 bytes of every row) and walks the rows with a
+  // stride of R = threads / 18; consecutive threads cover a row, then the next one: rows are contiguous, so global traffic is
+  // coalesced 16-byte accesses and no item needs a division.  (One (row, hand) item per thread and iteration was ~45 VALU
+  // instructions per element, most of them index arithmetic: the passes were instruction-issue-bound.)
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int HP = H / 2;
+  const int R = NT / HP, my_r = tid / HP, h2 = tid - my_r * HP;
+  const bool in_grid = my_r < R;  // the last threads of the block (NT is not a multiple of 18) sit the pair passes out
+  d2* rho0_2 = reinterpret_cast<d2*>(rho0);
+  d2* rho1_2 = reinterpret_cast<d2*>(rho1);
+  d2* yrow_2 = reinterpret_cast<d2*>(yrow);
+  d2* val_2 = reinterpret_cast<d2*>(val);
+  d2* sig_2 = reinterpret_cast<d2*>(sig);
+  const f2* lvals_2 = reinterpret_cast<const f2*>(lvals);
+  // value pair of node c as its parent reads it (lr = t_lrow[c], lv = the net's pair when c is a pseudo-leaf)
+  auto child_val2 = [&](int lr, f2 lv) {
+    if (lr >= 0) {  // query_value_net (:257-268)
+      const double ls = lsum[lr];
+      return d2{(double)(float)((double)lv[0] * ls), (double)(float)((double)lv[1] * ls)};
+    }
+    return val_2[(-1 - lr) * HP + h2];
   };
 
   // ---------------------------------------------------------------- reach of both players under sigma, level by level
@@ -173,26 +191,26 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     const int mover = root_player ^ ((lev - 1) & 1);
     double* rho_m = mover == 0 ? rho0 : rho1;  // reach of the player who acted: times sigma
     double* rho_n = mover == 0 ? rho1 : rho0;  // the other one's: copied
-    if (lev < nlev - 1) {  // rows are kept for nodes with children (the last level has none)
-      const int cnt = (n1 - n0) * H;
-      for (int i0 = tid; i0 < cnt; i0 += kU * NT) {
-        double rm[kU], rn[kU], sg[kU];
+    d2* rho_m2 = reinterpret_cast<d2*>(rho_m);
+    d2* rho_n2 = reinterpret_cast<d2*>(rho_n);
+    if (lev < nlev - 1 && in_grid) {  // rows are kept for nodes with children (the last level has none)
+      for (int nb = n0 + my_r; nb < n1; nb += kU * R) {
+        d2 rm[kU], rn[kU], sg[kU];
         int dst[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int i = min(i0 + u * NT, cnt - 1);
-          const int n = n0 + i / H, h = i % H;
+          const int n = min(nb + u * R, n1 - 1);
           const int w = t_pack[n];
-          dst[u] = (i0 + u * NT < cnt && pk_ir(w) >= 0) ? pk_ir(w) * H + h : -1;
-          rm[u] = rho_m[pk_pr(w) * H + h];
-          rn[u] = rho_n[pk_pr(w) * H + h];
-          sg[u] = sig[(n - 1) * H + h];
+          dst[u] = (nb + u * R < n1 && pk_ir(w) >= 0) ? pk_ir(w) * HP + h2 : -1;
+          rm[u] = rho_m2[pk_pr(w) * HP + h2];
+          rn[u] = rho_n2[pk_pr(w) * HP + h2];
+          sg[u] = sig_2[(n - 1) * HP + h2];
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
           if (dst[u] >= 0) {
-            rho_m[dst[u]] = rm[u] * sg[u];
-            rho_n[dst[u]] = rn[u];
+            rho_m2[dst[u]] = rm[u] * sg[u];
+            rho_n2[dst[u]] = rn[u];
           }
       }
     }
@@ -294,65 +312,64 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
     const bool mine = (root_player ^ (lev & 1)) == t;
-    // node values: one item per (node, hand), sequential over the actions in ascending order; the children's operands are
-    // requested eight at a time (a pseudo-leaf's value comes from the net's rows in global memory)
-    for (int i = tid; i < (n1 - n0) * H; i += NT) {
-      const int n = n0 + i / H, h = i % H;
-      const int c0 = t_cb[n], c1 = t_ce[n];
-      if (c0 == c1) continue;
-      // a pseudo-leaf's value comes from the net's rows in global memory: twelve children's are requested before the first is
-      // used (all 24 at once spilled registers to scratch: 24 k cycles for this pass at the root)
-      constexpr int kC = 12;
-      double x = 0.0;
-      for (int cb = c0; cb < c1; cb += kC) {
-        int lr[kC];
-        float lvf[kC];
+    d2* rho_t2 = reinterpret_cast<d2*>(rho_t);
+    // node values: one item per (node, hand pair), sequential over the actions in ascending order.  A pseudo-leaf's value comes
+    // from the net's rows in global memory: twelve children's are requested before the first is used (all 24 at once spilled
+    // registers), unconditionally and from a row that exists (a load under a condition is a branch, and loads in different
+    // basic blocks are not requested together)
+    if (in_grid) {
+      for (int n = n0 + my_r; n < n1; n += R) {
+        const int c0 = t_cb[n], c1 = t_ce[n];
+        if (c0 == c1) continue;
+        constexpr int kC = 12;
+        d2 x = {0.0, 0.0};
+        for (int cb = c0; cb < c1; cb += kC) {
+          int lr[kC];
+          f2 lvf[kC];
 #pragma unroll
-        for (int u = 0; u < kC; ++u) lr[u] = t_lrow[min(cb + u, c1 - 1)];
-        // unconditional loads from a row that exists (row 0 when the child is not a pseudo-leaf): a load under a condition is a
-        // branch, and loads in different basic blocks are not requested together
+          for (int u = 0; u < kC; ++u) lr[u] = t_lrow[min(cb + u, c1 - 1)];
 #pragma unroll
-        for (int u = 0; u < kC; ++u) lvf[u] = lvals[max(lr[u], 0) * H + h];
+          for (int u = 0; u < kC; ++u) lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
 #pragma unroll
-        for (int u = 0; u < kC; ++u)
-          if (cb + u < c1) {
-            const double v = lr[u] >= 0 ? (double)(float)((double)lvf[u] * lsum[lr[u]]) : val[(-1 - lr[u]) * H + h];
-            if (mine) x += v * sig[(cb + u - 1) * H + h];
-            else x += v;
-          }
+          for (int u = 0; u < kC; ++u)
+            if (cb + u < c1) {
+              const d2 v = child_val2(lr[u], lvf[u]);
+              if (mine) x += v * sig_2[(cb + u - 1) * HP + h2];
+              else x += v;
+            }
+        }
+        val_2[(-1 - t_lrow[n]) * HP + h2] = x;
       }
-      val[(-1 - t_lrow[n]) * H + h] = x;
     }
     RBL_F2();  // node values
     __syncthreads();
     if (!mine) continue;
-    // regrets of the edges into the level below; sigma receives the clamped regrets
-    {
-      const int cnt = (c_hi - c_lo) * H;
-      for (int i0 = tid; i0 < cnt; i0 += kG * NT) {  // every global operand of the thread's items in one round trip
-        double q[kG];
-        float lvf[kG];
+    // regrets of the edges into the level below; sigma receives the clamped regrets.  Every global operand of the thread's rows
+    // in one round trip (clamped, unconditional: straight-line code)
+    if (in_grid) {
+      d2* greg_2 = reinterpret_cast<d2*>(g_reg);
+      for (int cb = c_lo + my_r; cb < c_hi; cb += kG * R) {
+        d2 q[kG];
+        f2 lvf[kG];
         int lr[kG];
 #pragma unroll
-        for (int u = 0; u < kG; ++u) {  // clamped, unconditional: straight-line code
-          const int i = min(i0 + u * NT, cnt - 1);
-          const int c = c_lo + i / H, h = i % H;
-          q[u] = g_reg[(c - 1) * H + h];
+        for (int u = 0; u < kG; ++u) {
+          const int c = min(cb + u * R, c_hi - 1);
+          q[u] = greg_2[(c - 1) * HP + h2];
           lr[u] = t_lrow[c];
-          lvf[u] = lvals[max(lr[u], 0) * H + h];
+          lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
         }
 #pragma unroll
         for (int u = 0; u < kG; ++u)
-          if (i0 + u * NT < cnt) {
-            const int i = i0 + u * NT;
-            const int c = c_lo + i / H, h = i % H;
-            const int e = (c - 1) * H + h;
-            const double cv = lr[u] >= 0 ? (double)(float)((double)lvf[u] * lsum[lr[u]]) : val[(-1 - lr[u]) * H + h];
-            double qq = q[u];
+          if (cb + u * R < c_hi) {
+            const int c = cb + u * R;
+            const int e = (c - 1) * HP + h2;
+            const d2 cv = child_val2(lr[u], lvf[u]);
+            d2 qq = q[u];
             qq += cv;
-            qq -= val[pk_pv(t_pack[c]) * H + h];
-            sig[e] = qq > kEps ? qq : kEps;
-            g_reg[e] = qq * (qq > 0 ? a.pos : a.neg);
+            qq -= val_2[pk_pv(t_pack[c]) * HP + h2];
+            sig_2[e] = d2{qq[0] > kEps ? qq[0] : kEps, qq[1] > kEps ? qq[1] : kEps};
+            greg_2[e] = d2{qq[0] * (qq[0] > 0 ? a.pos : a.neg), qq[1] * (qq[1] > 0 ? a.pos : a.neg)};
           }
       }
     }
@@ -361,50 +378,57 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // row sums, sequential over the actions; parked in the (dead) rho_t row.  m / s below is hipcc's f64 division sequence
     // with its denominator-only part (v_rcp_f64 + two Newton steps) done here once per (node, hand); v_div_scale / v_div_fixup
     // are the identity for these operands (1e-80 <= m <= s; scripts/micro/div_shared_rcp.hip checks 3e9 cases against `/`)
-    for (int i = tid; i < (n1 - n0) * H; i += NT) {
-      const int n = n0 + i / H, h = i % H;
-      const int c0 = t_cb[n], c1 = t_ce[n];
-      if (c0 == c1) continue;
-      double s = 0.0;
-      for (int cb = c0; cb < c1; cb += 8) {
-        double m8[8];
+    if (in_grid) {
+      for (int n = n0 + my_r; n < n1; n += R) {
+        const int c0 = t_cb[n], c1 = t_ce[n];
+        if (c0 == c1) continue;
+        d2 s = {0.0, 0.0};
+        for (int cb = c0; cb < c1; cb += 8) {
+          d2 m8[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) m8[u] = sig[(min(cb + u, c1 - 1) - 1) * H + h];
+          for (int u = 0; u < 8; ++u) m8[u] = sig_2[(min(cb + u, c1 - 1) - 1) * HP + h2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (cb + u < c1) s += m8[u];
+          for (int u = 0; u < 8; ++u)
+            if (cb + u < c1) s += m8[u];
+        }
+        d2 y;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          double yy = __builtin_amdgcn_rcp(s[k]);
+          double er = __builtin_fma(-s[k], yy, 1.0);
+          yy = __builtin_fma(yy, er, yy);
+          er = __builtin_fma(-s[k], yy, 1.0);
+          y[k] = __builtin_fma(yy, er, yy);
+        }
+        const int ir = pk_ir(t_pack[n]);
+        rho_t2[ir * HP + h2] = s;
+        yrow_2[ir * HP + h2] = y;
       }
-      double yy = __builtin_amdgcn_rcp(s);
-      double er = __builtin_fma(-s, yy, 1.0);
-      yy = __builtin_fma(yy, er, yy);
-      er = __builtin_fma(-s, yy, 1.0);
-      const int ir = pk_ir(t_pack[n]);
-      rho_t[ir * H + h] = s;
-      yrow[ir * H + h] = __builtin_fma(yy, er, yy);
     }
     RBL_F2();  // row sums
     __syncthreads();
-    {
-      const int cnt = (c_hi - c_lo) * H;
-      for (int i0 = tid; i0 < cnt; i0 += kU * NT) {
-        double s[kU], y[kU], m[kU];
-        int e[kU];
+    if (in_grid) {
+      for (int cb = c_lo + my_r; cb < c_hi; cb += kU * R) {
+        d2 s[kU], y[kU], m[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int i = min(i0 + u * NT, cnt - 1);
-          const int c = c_lo + i / H, h = i % H;
+          const int c = min(cb + u * R, c_hi - 1);
           const int pr = pk_pr(t_pack[c]);
-          e[u] = i0 + u * NT < cnt ? (c - 1) * H + h : -1;
-          s[u] = rho_t[pr * H + h];
-          y[u] = yrow[pr * H + h];
-          m[u] = sig[(c - 1) * H + h];
+          s[u] = rho_t2[pr * HP + h2];
+          y[u] = yrow_2[pr * HP + h2];
+          m[u] = sig_2[(c - 1) * HP + h2];
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
-          if (e[u] >= 0) {
-            const double q0 = m[u] * y[u];
-            const double rem = __builtin_fma(-s[u], q0, m[u]);
-            sig[e[u]] = __builtin_fma(rem, y[u], q0);
+          if (cb + u * R < c_hi) {
+            d2 o;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const double q0 = m[u][k] * y[u][k];
+              const double rem = __builtin_fma(-s[u][k], q0, m[u][k]);
+              o[k] = __builtin_fma(rem, y[u][k], q0);
+            }
+            sig_2[(cb + u * R - 1) * HP + h2] = o;
           }
       }
     }
@@ -424,22 +448,23 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   for (int lev = 1; lev < nlev - 1; ++lev) {
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const bool own = (root_player ^ ((lev - 1) & 1)) == t;
-    const int cnt = (n1 - n0) * H;
-    for (int i0 = tid; i0 < cnt; i0 += kU * NT) {
-      double r[kU], sg[kU];
-      int dst[kU];
+    d2* rho_t2 = reinterpret_cast<d2*>(rho_t);
+    if (in_grid) {
+      for (int nb = n0 + my_r; nb < n1; nb += kU * R) {
+        d2 r[kU], sg[kU];
+        int dst[kU];
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const int i = min(i0 + u * NT, cnt - 1);
-        const int n = n0 + i / H, h = i % H;
-        const int w = t_pack[n];
-        dst[u] = (i0 + u * NT < cnt && pk_ir(w) >= 0) ? pk_ir(w) * H + h : -1;
-        r[u] = rho_t[pk_pr(w) * H + h];
-        sg[u] = sig[(n - 1) * H + h];
+        for (int u = 0; u < kU; ++u) {
+          const int n = min(nb + u * R, n1 - 1);
+          const int w = t_pack[n];
+          dst[u] = (nb + u * R < n1 && pk_ir(w) >= 0) ? pk_ir(w) * HP + h2 : -1;
+          r[u] = rho_t2[pk_pr(w) * HP + h2];
+          sg[u] = sig_2[(n - 1) * HP + h2];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (dst[u] >= 0) rho_t2[dst[u]] = own ? r[u] * sg[u] : r[u];
       }
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (dst[u] >= 0) rho_t[dst[u]] = own ? r[u] * sg[u] : r[u];
     }
     __syncthreads();
   }
@@ -447,32 +472,32 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 
   // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
   {
-    double* snap = a.snapshot + lane_e;
-    const int cnt = E * H;
-    for (int i0 = tid; i0 < cnt; i0 += kG * NT) {
-      double x[kG];
-      bool own[kG];
+    d2* snap_2 = reinterpret_cast<d2*>(a.snapshot + lane_e);
+    d2* gsum_2 = reinterpret_cast<d2*>(g_sum);
+    d2* gsig_2 = reinterpret_cast<d2*>(g_sig);
+    const d2* rho_t2 = reinterpret_cast<const d2*>(rho_t);
+    if (in_grid) {
+      for (int cb = 1 + my_r; cb < N; cb += kG * R) {
+        d2 x[kG];
 #pragma unroll
-      for (int u = 0; u < kG; ++u) {  // clamped, unconditional: straight-line code
-        const int i = min(i0 + u * NT, cnt - 1);
-        own[u] = (root_player ^ pk_pdp(t_pack[1 + i / H])) == t;
-        x[u] = g_sum[i];
-      }
+        for (int u = 0; u < kG; ++u) x[u] = gsum_2[(min(cb + u * R, N - 1) - 1) * HP + h2];  // clamped, unconditional
 #pragma unroll
-      for (int u = 0; u < kG; ++u)
-        if (i0 + u * NT < cnt) {
-          const int i = i0 + u * NT;
-          const int h = i % H;
-          const double s = sig[i];
-          if (own[u]) {
-            double xx = x[u];
-            xx *= a.strat;
-            xx += rho_t[pk_pr(t_pack[1 + i / H]) * H + h] * s;
-            g_sum[i] = xx;
-            g_sig[i] = s;
+        for (int u = 0; u < kG; ++u)
+          if (cb + u * R < N) {
+            const int c = cb + u * R;
+            const int e = (c - 1) * HP + h2;
+            const int w = t_pack[c];
+            const d2 s = sig_2[e];
+            if ((root_player ^ pk_pdp(w)) == t) {
+              d2 xx = x[u];
+              xx *= a.strat;
+              xx += rho_t2[pk_pr(w) * HP + h2] * s;
+              gsum_2[e] = xx;
+              gsig_2[e] = s;
+            }
+            if (snap_now) snap_2[e] = s;
           }
-          if (snap_now) snap[i] = s;
-        }
+      }
     }
   }
   RBL_STAMP();  // 7: write-back
@@ -513,35 +538,48 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // (x + eps) / s is hipcc's f64 division sequence minus v_div_scale / v_div_fixup, the identity here
     // (1e-80 <= x + eps <= s <= H + 1)
     float* gq = a.queries + (size_t)row_off * Q;
-    const int cnt = L * Q;
-    for (int i0 = tid; i0 < cnt; i0 += kU * NT) {
-      double num[kU], s[kU], y[kU];
-      float flat[kU];
-      int kind[kU];  // -1: nothing to store, 0: `flat`, 1: the quotient
+    // the head of a row: player to move, traverser, one-hot last bid
+    for (int i = tid; i < L * (2 + A); i += NT) {
+      const int k = i / (2 + A), j = i - k * (2 + A);
+      const int rec = t_qrec[k];
+      gq[(size_t)k * Q + j] = j == 0 ? (float)((rec >> 18) & 1) : (j == 1 ? (float)a.next_trav : (j - 2 == (rec >> 19) ? 1.0f : 0.0f));
+    }
+    // the two reach vectors: a pair of hands of BOTH players per thread and row
+    if (in_grid) {
+      for (int kb = my_r; kb < L; kb += kU * R) {
+        d2 r0[kU], r1[kU], sg[kU], q4[kU][2];
+        int pm[kU];
 #pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        const int i = min(i0 + u * NT, cnt - 1);
-        const int k = i / Q, j = i - k * Q;
-        const int rec = t_qrec[k];
-        const int n = rec & 511, pr = (rec >> 9) & 255, pm = (rec >> 17) & 1;
-        const int jj = max(j - 2 - A, 0);
-        const int wh = jj / H, h = jj % H;  // player whose reach this is
-        const bool acted = wh == pm;
-        const double r = (wh == 0 ? rho0 : rho1)[pr * H + h];
-        const double sg = acted ? sig[(n - 1) * H + h] : 1.0;
-        num[u] = (acted ? r * sg : r) + kEps;
-        s[u] = qs[4 * k + (acted ? 0 : 2)];
-        y[u] = qs[4 * k + (acted ? 1 : 3)];
-        flat[u] = j == 0 ? (float)((rec >> 18) & 1) : (j == 1 ? (float)a.next_trav : (j - 2 == (rec >> 19) ? 1.0f : 0.0f));
-        kind[u] = i0 + u * NT < cnt ? (j < 2 + A ? 0 : 1) : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < kU; ++u)
-        if (kind[u] >= 0) {
-          const double q0 = num[u] * y[u];
-          const double rem = __builtin_fma(-s[u], q0, num[u]);
-          gq[i0 + u * NT] = kind[u] == 0 ? flat[u] : (float)__builtin_fma(rem, y[u], q0);
+        for (int u = 0; u < kU; ++u) {
+          const int k = min(kb + u * R, L - 1);
+          const int rec = t_qrec[k];
+          const int n = rec & 511, pr = (rec >> 9) & 255;
+          pm[u] = (rec >> 17) & 1;
+          r0[u] = rho0_2[pr * HP + h2];
+          r1[u] = rho1_2[pr * HP + h2];
+          sg[u] = sig_2[(n - 1) * HP + h2];
+          q4[u][0] = reinterpret_cast<const d2*>(qs)[2 * k];      // sum, reciprocal of the player who acted
+          q4[u][1] = reinterpret_cast<const d2*>(qs)[2 * k + 1];  // ... of the other one
         }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (kb + u * R < L) {
+            float* row = gq + (size_t)(kb + u * R) * Q + 2 + A + 2 * h2;
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) {
+              const bool acted = wh == pm[u];
+              const d2 r = wh == 0 ? r0[u] : r1[u];
+              const d2 sy = acted ? q4[u][0] : q4[u][1];
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {
+                const double num = (acted ? r[k] * sg[u][k] : r[k]) + kEps;
+                const double q0 = num * sy[1];
+                const double rem = __builtin_fma(-sy[0], q0, num);
+                row[wh * H + k] = (float)__builtin_fma(rem, sy[1], q0);
+              }
+            }
+          }
+      }
     }
   }
   RBL_STAMP();  // 8: queries
@@ -551,7 +589,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 }  // namespace
 
 size_t cfr_flat_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
-  const size_t d = (size_t)3 * NI * H + (size_t)(N - L) * H + (size_t)5 * L + (size_t)(N - 1) * H;  // doubles
+  const size_t d = (size_t)3 * NI * H + (size_t)(N - L) * H + (size_t)((L + 1) & ~1) + (size_t)4 * L + (size_t)(N - 1) * H;  // doubles
   const size_t b = d * 8 + (((size_t)7 * N + 2 * L + T + 1) & ~(size_t)1) * 4 + (size_t)faces * 16;
   return (b + 15) & ~(size_t)15;
 }
