@@ -113,41 +113,45 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     const d2* gs = reinterpret_cast<const d2*>(g_sig);
     d2* ls = reinterpret_cast<d2*>(sig);
     const int EW = E * H / 2;  // H is even
-    // batches of independent loads before their stores (one load -> store per iteration paid a memory round trip each)
-    for (int i0 = tid; i0 < EW; i0 += 12 * NT) {
-      d2 v[12];
-#pragma unroll
-      for (int u = 0; u < 12; ++u) v[u] = gs[min(i0 + u * NT, EW - 1)];
-#pragma unroll
-      for (int u = 0; u < 12; ++u)
-        if (i0 + u * NT < EW) ls[i0 + u * NT] = v[u];
+    // sigma: global -> LDS without a stop in registers (global_load_lds_dwordx4: lane l of a wave lands at base + 16 l,
+    // scripts/micro/global_load_lds.hip): a wave requests its 1 KB chunks back to back and the whole copy is in flight at
+    // once.  (Through registers, 12 pieces per thread at a time, it was four memory round trips: 8 k cycles at the root.)
+    {
+      const int wave = tid >> 6, ln = tid & 63, nw = NT >> 6;
+      const int full = EW / 64;  // 1 KB chunks
+      for (int c = wave; c < full; c += nw)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gs + c * 64 + ln),
+                                         (__attribute__((address_space(3))) void*)(ls + c * 64), 16, 0, 0);
+      if (tid < EW - full * 64) ls[full * 64 + tid] = gs[full * 64 + tid];
     }
     const int* gp = a.parent + node_off;
     const int* ga = a.act + node_off;
     const int* gb = a.cb + node_off;
     const int* ge = a.ce + node_off;
     const int* gd = a.depth + node_off;
-    const int* gi = a.irank + node_off;
     const int* gl = a.leaf_row + node_off;
     const int* gv = a.vrow + node_off;
+    const int* gk = a.pack + node_off;
     for (int i = tid; i < N; i += NT) {
-      const int p = gp[i], lr = gl[i], vr = gv[i], ir = gi[i];
-      const int pp = max(p, 0);
-      // second round trip: the parent's rows (once per step; the passes below then need one table word per item)
-      const int pir = gi[pp], pvr = gv[pp], pd = gd[pp];
-      t_parent[i] = p;
+      const int lr = gl[i];
+      t_parent[i] = gp[i];
       t_act[i] = ga[i];
       t_cb[i] = gb[i];
       t_ce[i] = ge[i];
       t_depth[i] = gd[i];
-      t_pack[i] = (pir & 255) | ((pvr & 255) << 8) | ((pd & 1) << 16) | ((ir + 1) << 17);
-      t_lrow[i] = lr >= 0 ? lr : -1 - vr;
+      t_pack[i] = gk[i];
+      t_lrow[i] = lr >= 0 ? lr : -1 - gv[i];
       if (lr >= 0) t_leaf[lr] = i;
     }
-    if (tid < 2 * FACES) {
-      const int8_t* mrow = a.matches + (tid >> 1) * H;
+    if (tid < 2 * FACES) {  // H = 36 bytes per face = 9 aligned words, all requested before the first is used
+      static_assert(H % 4 == 0, "match rows are read as words");
+      const int* mrow = reinterpret_cast<const int*>(a.matches + (tid >> 1) * H);
+      int w[H / 4];
+#pragma unroll
+      for (int q = 0; q < H / 4; ++q) w[q] = mrow[q];
       unsigned long long bits = 0;
-      for (int h = 0; h < H; ++h) bits |= (unsigned long long)(mrow[h] == (tid & 1) + 1) << h;
+#pragma unroll
+      for (int h = 0; h < H; ++h) bits |= (unsigned long long)(((w[h / 4] >> (8 * (h % 4))) & 255) == (tid & 1) + 1) << h;
       t_mask[tid] = bits;
     }
     for (int i = tid; i < T; i += NT) t_term[i] = (a.terms + shc->term_off)[i];
@@ -157,6 +161,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       rho1[tid] = t == 1 ? bel_t : bel[H + tid];
       rmean_t = rmean[t * H + tid];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads are not tied to a register the compiler could wait on
     __syncthreads();
   }
   RBL_STAMP();  // 1: staged

@@ -30,7 +30,8 @@ struct CfrArgs {
   const int* terms;
   const int* irank;     // node -> index of its reach row (root / nodes with children), -1 otherwise (cfr_rows_kernel)
   const int* leaf_row;  // node -> net row within the lane for pseudo-leaves, -1 otherwise (cfr_rows_kernel)
-  const int* vrow;      // node -> rank among the nodes that are not pseudo-leaves, -1 for those (cfr_rows_kernel<GS>)
+  const int* vrow;      // node -> rank among the nodes that are not pseudo-leaves, -1 for those (cfr_flat_kernel)
+  const int* pack;      // node -> packed rows of its parent (tables.h: ShapeTables::pack; cfr_flat_kernel)
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
   const int8_t* wave_tabs;  // cfr_wave_kernel: per shape parent | act | cb | ce | depth | irank (N bytes each) | leaf nodes (L) |
   const int* wave_tab_off;  //                  terminal nodes (T) as one 4-byte aligned blob; byte offset of each shape's blob

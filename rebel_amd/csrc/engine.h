@@ -178,7 +178,7 @@ class Engine {
   hipStream_t part_stream(int part) const { return part == 0 ? stream_ : part == 1 ? stream2_ : stream_x_[part - 2]; }
 
   DevBuf<ShapeDev> d_shapes_;
-  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_, d_vrow_;
+  DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_, d_vrow_, d_pack_;
   DevBuf<int8_t> d_matches_, d_wave_tabs_;
   DevBuf<int> d_wave_tab_off_;
   DevBuf<int> d_shape_epar_;

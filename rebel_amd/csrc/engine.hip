@@ -106,6 +106,7 @@ void Engine::construct() {
   d_irank_.upload(padded(tabs_.irank), stream_);
   d_leaf_row_.upload(padded(tabs_.leaf_row), stream_);
   d_vrow_.upload(padded(tabs_.vrow), stream_);
+  d_pack_.upload(padded(tabs_.pack), stream_);
   {  // byte blobs of the per-shape tables in the one-wavefront kernel's LDS layout (staged with dword loads)
     std::vector<int8_t> blob;
     std::vector<int> off;
@@ -705,6 +706,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.irank = d_irank_.p;
   a.leaf_row = d_leaf_row_.p;
   a.vrow = d_vrow_.p;
+  a.pack = d_pack_.p;
   a.matches = d_matches_.p;
   a.wave_tabs = d_wave_tabs_.p;
   a.wave_tab_off = d_wave_tab_off_.p;

@@ -80,7 +80,10 @@ struct ShapeDev {
 struct ShapeTables {
   std::vector<ShapeDev> shapes;  // index = root_last_bid + 1
   std::vector<int> parent, act, cb, ce, depth, leaf_row, irank, leaves, terms;
-  std::vector<int> vrow;  // node -> its rank among the nodes that are NOT pseudo-leaves (-1 for pseudo-leaves): cfr_rows_kernel<GS>
+  std::vector<int> vrow;  // node -> its rank among the nodes that are NOT pseudo-leaves (-1 for pseudo-leaves): cfr_flat_kernel
+  // node -> reach row of its parent | value row of its parent << 8 | depth parity of its parent << 16 | (own reach row + 1)
+  // << 17 (cfr_flat_kernel: one table word per item instead of a chain of look-ups); 0 in the low 17 bits for the root
+  std::vector<int> pack;
   int max_N = 0, max_L = 0, max_T = 0;
 
   // has_net=false reproduces the reference's refusal to build a truncated tree without a value net
@@ -121,6 +124,11 @@ struct ShapeTables {
         t.leaf_row.push_back(row);
         t.vrow.push_back(row >= 0 ? -1 : i - s.L);
         t.irank.push_back((i == 0 || n.cb != n.ce) ? s.NI++ : -1);
+        {
+          const int p = std::max(n.parent, 0);  // BFS order: the parent's entries exist already
+          const int pir = t.irank[s.node_off + p], pvr = t.vrow[s.node_off + p], pd = t.depth[s.node_off + p];
+          t.pack.push_back((pir & 255) | ((pvr & 255) << 8) | ((pd & 1) << 16) | ((t.irank.back() + 1) << 17));
+        }
       }
       s.nlev = lev + 1;
       for (int d = s.nlev; d <= kMaxLevels; ++d) s.lev_off[d] = s.N;
