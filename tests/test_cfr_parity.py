@@ -367,6 +367,45 @@ def test_2d6f_root_2048_iterations_bit_exact(port):
             assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
 
 
+@pytest.mark.parametrize("flat", [1, 0])
+def test_2d6f_kernels_agree_and_the_flat_one_runs(flat, port, monkeypatch):
+    """2 dice x 6 faces has two step kernels: cfr_flat_kernel (element-parallel, sigma in LDS: the default) and
+    cfr_rows_kernel<GS> (RBL_CFR_FLAT=0).  Both reach the oracle's state bit for bit on a mix of subgame sizes incl. DCFR
+    discounts and per-lane stop iterations, and the engine reports which one it launched (no silent fallback)."""
+    from oracle import orc
+    from rebel_amd import capi
+
+    monkeypatch.setenv("RBL_CFR_FLAT", str(flat))
+    d, f, iters = 2, 6, 37
+    kw = dict(num_iters=iters, max_depth=2, linear_update=False, use_cfr=True, dcfr=True, dcfr_alpha=1.5, dcfr_beta=0.5,
+              dcfr_gamma=2.0)
+    H = port.num_hands(d, f)
+    rng = np.random.default_rng(11)
+    roots = [-1, 0, 3, 9, 14, 20, 22, 23 - 1, -1]
+    players = [0, 1, 0, 1, 0, 1, 0, 1, 1]
+    B = len(roots)
+    beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
+    act = [5, 36, 0, 17, 36, 2, 9, 1, 30]
+    e = capi.Engine(d, f, capi.make_params(**kw), max_lanes=B)
+    e.set_net_synthetic()
+    e.reset(roots, players, beliefs, act)
+    e.multistep()
+    assert e.stats()["cfr_kernel"] == (4 if flat else 3)
+    for b in range(B):
+        o = port.solver(d, f, orc.make_params(**kw), roots[b], players[b], beliefs[b], orc.NET_SYNTHETIC)
+        for it in range(iters):
+            o.step(it % 2)
+            if it + 1 == act[b]:
+                snap = o.get(orc.GET_LAST)
+        if act[b] == 0:
+            snap = port.solver(d, f, orc.make_params(**kw), roots[b], players[b], beliefs[b], orc.NET_SYNTHETIC).get(orc.GET_LAST)
+        for w, ow in [(capi.GET_LAST, orc.GET_LAST), (capi.GET_SUM, orc.GET_SUM), (capi.GET_REGRETS, orc.GET_REGRETS)]:
+            assert np.array_equal(e.get(b, w), o.get(ow)), (b, w)
+        assert np.array_equal(e.get_snapshot(b), snap), b
+        for pl in (0, 1):
+            assert np.array_equal(e.hand_values(b, pl), o.hand_values(pl))
+
+
 @pytest.mark.parametrize("name", ["1d6f_root_syn_1024", "2d3f_bid2_p1_syn_256", "1d4f_dcfr_syn_64"])
 def test_row_kernel_fallback_bit_exact(name, port, monkeypatch):
     """RBL_CFR_WAVE=0: the row-per-thread kernel (the fallback of the one-wavefront kernel, and the kernel deeper subgames
