@@ -381,7 +381,7 @@ def test_2d6f_kernels_agree_and_the_flat_one_runs(flat, port, monkeypatch):
               dcfr_gamma=2.0)
     H = port.num_hands(d, f)
     rng = np.random.default_rng(11)
-    roots = [-1, 0, 3, 9, 14, 20, 22, 23 - 1, -1]
+    roots = [-1, 0, 3, 9, 14, 20, 22, 23, -1]  # 23: only "liar" is left (two nodes, no pseudo-leaf)
     players = [0, 1, 0, 1, 0, 1, 0, 1, 1]
     B = len(roots)
     beliefs = rng.dirichlet(np.ones(H), size=(B, 2))
