@@ -252,9 +252,6 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       for (int g0 = g; g0 < T; g0 += NT / 4) {
         const int n = t_term[g0];
         if (n < n0 || n >= n1) continue;  // uniform over the four threads of a group
-#ifdef RBL_SKIP_TERM
-        if (a.dbg) continue;
-#endif
         const int pr = pk_pr(t_pack[n]);
         const double* ro = (times_sigma ? rho_m : rho_n) + pr * H;
         const double* sg = sig + (n - 1) * H;
