@@ -10,18 +10,25 @@
 // (Halving the LDS footprint to get two lanes per CU made it slower: 153 k cycles -- the extra lanes only queue at the
 // addresser.)  Here instead:
 //   * every pass that is elementwise in the hand index -- reach products, node values (sequential over the children),
-//     regret update, regret matching, normalisation, sum_strategies, the query rows -- runs over (row, hand) ITEMS spread
-//     over 512 threads: consecutive threads touch consecutive addresses, global traffic is coalesced;
-//   * only what is sequential over the HANDS stays one thread per row, on LDS rows: a leaf's reach sum, a terminal's match
-//     histogram, the two normalisation sums of a query row;
-//   * sigma lives in LDS for the whole step (93 KB at the root): read from global once, the traverser's rows written back
-//     once; regrets and sum_strategies are touched once (read + write) by the pass that needs them;
+//     regret update, regret matching, normalisation, sum_strategies, the query rows -- runs over (row, hand PAIR) items: a
+//     thread owns 16 bytes of every row and walks the rows with a constant stride, so consecutive threads touch consecutive
+//     addresses (coalesced global traffic, conflict-free LDS) and no item needs a division;
+//   * only what is sequential over the HANDS stays one thread per row, on LDS rows: a leaf's reach sum, the two normalisation
+//     sums of a query row, and a terminal's match histogram, which four threads share (one per match bin + the total);
+//   * sigma lives in LDS for the whole step (93 KB at the root, staged with LDS-direct loads): read from global once, the
+//     traverser's rows written back once; regrets and sum_strategies are touched once (read + write) by the pass that needs them;
 //   * a pseudo-leaf keeps ONE double (the reach sum that scales the net's row); its value row float(net row x sum) is
 //     recomputed where it is read -- the same expression, bit for bit.  Value rows exist for nodes with children and
-//     terminals only (49 of 325 at the root).
-// LDS at the root: 143 KB (one lane per CU, 8 waves); a 160-node tree needs 70 KB (two lanes).  Arithmetic is
-// operation-for-operation what cfr_rows_kernel / cfr_kernels.hip do (same operands, same order, -ffp-contract=off):
-// tests/test_cfr_parity.py and tests/test_selfplay_parity.py run the 2 dice x 6 faces cases against the oracle through it.
+//     terminals only (49 of 325 at the root);
+//   * every pass is "gather, compute, scatter": all operands of a batch of rows are requested before the first is used,
+//     unconditionally and clamped.  hipcc keeps LDS loads behind earlier LDS stores (the arrays of a dynamic LDS block may
+//     alias) and does not batch loads across basic blocks, so a pass written "load, compute, store" per item is one LDS or
+//     memory round trip per item -- with 16 waves per CU nothing hides that (first version of this kernel: 137 k cycles).
+// The workgroup is sized to the largest tree of its launch segment (1024 / 512 / 256 / 128 threads: engine.h), LDS at the
+// root is 147 KB (one lane per CU, 16 waves); 105 VGPRs, no scratch.  Measured: root lane 115 k -> 69 k cycles per step,
+// 2 dice x 6 faces self-play 3.5 -> 4.8 M it/s (profiles/r03_bench_2d6f.txt).  Arithmetic is operation-for-operation what
+// cfr_rows_kernel / cfr_kernels.hip do (same operands, same order, -ffp-contract=off): tests/test_cfr_parity.py and
+// tests/test_selfplay_parity.py run the 2 dice x 6 faces cases against the oracle through it.
 //
 // Reference: CFR::step and its helpers, /root/reference/csrc/liars_dice/subgame_solving.cc:538-664; leaf queries :253-269,
 // terminal payoffs :80-98, :765-789.

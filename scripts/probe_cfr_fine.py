@@ -1,4 +1,7 @@
-"""Developer aid: raw stamps of the flat CFR kernel built with -DRBL_FINE_STAMPS (RBL_CFR_DBG=1)."""
+"""Developer aid: raw stamps of the flat CFR kernel (RBL_CFR_DBG=1).  Build cfr_flat_kernel.hip with -DRBL_FINE=1 (stamps
+inside the reach phase: rows, pseudo-leaves, terminals, barrier per level) or -DRBL_FINE=2 (inside the bottom-up sweep and the
+query phase) and link it into a scratch copy of librebel_hip.so; the product build has 9 stamps (scripts/probe_cfr_phases_2d6f.py).
+STEPS=n picks the traverser parity of the last step."""
 import os
 import sys
 
