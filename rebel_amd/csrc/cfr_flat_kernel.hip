@@ -239,10 +239,10 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       const double* sg = sig + (n - 1) * H;
       double s = 0.0;
       if (times_sigma) {
-#pragma unroll 6
+#pragma unroll 12
         for (int h = 0; h < H; ++h) s += ro[h] * sg[h];
       } else {
-#pragma unroll 6
+#pragma unroll 12
         for (int h = 0; h < H; ++h) s += ro[h];
       }
       lsum[lr] = s;
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
         const unsigned long long m1 = t_mask[2 * face], m2 = t_mask[2 * face + 1];
         const unsigned long long mine_mask = role == 3 ? ~0ull : (role == 0 ? ~(m1 | m2) : (role == 1 ? m1 : m2));
         double acc = 0.0;
-#pragma unroll 6
+#pragma unroll 12
         for (int h = 0; h < H; ++h) {
           double r = ro[h];
           if (times_sigma) r = r * sg[h];
@@ -523,9 +523,9 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       const double* rn = (pm == 0 ? rho1 : rho0) + pr * H;
       const double* sg = sig + (n - 1) * H;
       double sm = 0, sn = 0;
-#pragma unroll 6
+#pragma unroll 12
       for (int h = 0; h < H; ++h) sm += rm[h] * sg[h] + kEps;
-#pragma unroll 6
+#pragma unroll 12
       for (int h = 0; h < H; ++h) sn += rn[h] + kEps;
       double y = __builtin_amdgcn_rcp(sm);
       double er = __builtin_fma(-sm, y, 1.0);
