@@ -264,7 +264,8 @@ def main():
             "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
         }
         for key, kern in (("roofline", ("mlp_resident_kernel", "mlp_pipe_kernel")), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
-            tr = pmc_traffic(kern)
+            # the committed PMC passes were taken on the headline configuration: other games report traffic = null
+            tr = pmc_traffic(kern) if (a.dice, a.faces, a.iters) == (1, 6, 1024) else None
             if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
                 scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0
                 out[key]["traffic"] = tr["bytes"] * scale
