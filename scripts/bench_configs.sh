@@ -11,4 +11,5 @@ run --dice 1 --faces 4 --iters 1024 --lanes 16384 --steps 6 --warmup 3
 run --dice 2 --faces 3 --iters 1024 --lanes 16384 --steps 4 --warmup 3
 run --dice 2 --faces 6 --iters 2048 --lanes 1024 --steps 2 --warmup 1
 run --dice 2 --faces 6 --iters 2048 --lanes 2048 --steps 2 --warmup 1
+run --dice 2 --faces 6 --iters 2048 --lanes 4096 --steps 2 --warmup 1
 run --dice 1 --faces 6 --iters 1024 --lanes 4096 --steps 10 --warmup 4
