@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
     const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
     const bool mine = (root_player ^ (lev & 1)) == t;
+    const bool deepest = lev == nlev - 2;  // the children are the last level
     d2* rho_t2 = reinterpret_cast<d2*>(rho_t);
     // node values: one item per (node, hand pair), sequential over the actions in ascending order.  A pseudo-leaf's value comes
     // from the net's rows in global memory: twelve children's are requested before the first is used (all 24 at once spilled
@@ -337,8 +338,14 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
           f2 lvf[kC];
 #pragma unroll
           for (int u = 0; u < kC; ++u) lr[u] = t_lrow[min(cb + u, c1 - 1)];
+          if (deepest) {  // pseudo-leaves only exist on the last level: above it no child needs the net's rows (the unconditional
+            // loads were two memory round trips for the root's 24 children, whose values are all in LDS)
 #pragma unroll
-          for (int u = 0; u < kC; ++u) lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
+            for (int u = 0; u < kC; ++u) lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
+          } else {
+#pragma unroll
+            for (int u = 0; u < kC; ++u) lvf[u] = f2{0.f, 0.f};
+          }
 #pragma unroll
           for (int u = 0; u < kC; ++u)
             if (cb + u < c1) {
@@ -366,7 +373,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
           const int c = min(cb + u * R, c_hi - 1);
           q[u] = greg_2[(c - 1) * HP + h2];
           lr[u] = t_lrow[c];
-          lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
+          lvf[u] = deepest ? lvals_2[max(lr[u], 0) * HP + h2] : f2{0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < kG; ++u)
