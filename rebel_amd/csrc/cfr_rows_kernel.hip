@@ -563,6 +563,7 @@ size_t cfr_rows_lds_bytes(int N, int NI, int H, int L, int faces) {
   return (b + 15) & ~(size_t)15;
 }
 
+// (L is part of the signature the engine sizes both 2 dice x 6 faces kernels with; this one keeps a value row per node)
 size_t cfr_rows_global_lds_bytes(int N, int NI, int H, int /*L*/, int faces) {
   const size_t b = ((size_t)3 * NI * H + (size_t)N * H) * 8 + (size_t)7 * N * 4 + (size_t)faces * H;
   return (b + 15) & ~(size_t)15;

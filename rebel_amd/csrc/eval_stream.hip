@@ -281,14 +281,14 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
   const Rules& g = e.rules();
   const ShapeTables& tb = e.tables();
   const int H = g.H;
-  if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("exploitability_recursive: bad shard");
+  if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("recursive solve on the device: bad shard");
   RBL_HIP_CHECK(hipSetDevice(e.device()));
   hipStream_t st = e.stream();
   const int D = e.params().max_depth;
-  if (D < 1) throw std::runtime_error("exploitability_recursive: max_depth must be >= 1");
+  if (D < 1) throw std::runtime_error("recursive solve on the device: max_depth must be >= 1");
   const size_t lds = (size_t)e.emax() * H * sizeof(double) + (size_t)tb.max_N * sizeof(int32_t);
   if (lds > 160 * 1024)
-    throw std::runtime_error("exploitability_recursive: subgames of depth " + std::to_string(D) +
+    throw std::runtime_error("recursive solve on the device: subgames of depth " + std::to_string(D) +
                              " do not fit the scatter kernel's LDS image (" + std::to_string(lds) + " bytes)");
   RBL_HIP_CHECK(hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DevBuf<int32_t> d_node[2], d_lane_node, d_tag[2], d_lane_tag;
