@@ -197,32 +197,40 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     return val_2[(-1 - lr) * HP + h2];
   };
 
-  // ---------------------------------------------------------------- reach of both players under sigma, level by level
-  for (int lev = 1; lev < nlev; ++lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
-    const int mover = root_player ^ ((lev - 1) & 1);
-    double* rho_m = mover == 0 ? rho0 : rho1;  // reach of the player who acted: times sigma
-    double* rho_n = mover == 0 ? rho1 : rho0;  // the other one's: copied
-    d2* rho_m2 = reinterpret_cast<d2*>(rho_m);
-    d2* rho_n2 = reinterpret_cast<d2*>(rho_n);
-    if (lev < nlev - 1 && in_grid) {  // rows are kept for nodes with children (the last level has none)
+  // ---------------------------------------------------------------- reach of both players under sigma + leaf values, ONE pass.
+  // In a tree of depth <= 2 (all this kernel takes: the host checks nlev <= 3) the opponent acts on at most one edge of the
+  // path root -> leaf, so a leaf's opponent reach is the ROOT row times sigma of that edge (or the root row itself): the same
+  // two operands and the same single rounding as "level-1 row = root row x sigma, leaf = copy" or "level-1 row = copy, leaf =
+  // row x sigma".  Leaves therefore do not wait for the level-1 rows: those (needed by the query rows later), the
+  // pseudo-leaves' sums and the terminals' values are all computed side by side, one barrier for the whole phase.
+  {
+    const bool opp_at_root = root_player == opp;  // the opponent acts at the root (and the traverser at depth 1), or vice versa
+    const double* ro = opp == 0 ? rho0 : rho1;    // the opponent's root row
+    // which edge's sigma multiplies the root row on the way to leaf n (-1: none -- a depth-1 leaf below a traverser's root)
+    auto opp_edge = [&](int n) {
+      if (t_depth[n] == 1) return opp_at_root ? n - 1 : -1;
+      return opp_at_root ? t_parent[n] - 1 : n - 1;
+    };
+    if (nlev == 3 && in_grid) {  // rows of the depth-1 nodes with children
+      const int n0 = shc->lev_off[1], n1 = shc->lev_off[2];
+      d2* rho_m2 = root_player == 0 ? rho0_2 : rho1_2;  // the root's mover: times sigma
+      d2* rho_n2 = root_player == 0 ? rho1_2 : rho0_2;  // the other player: copied
       for (int nb = n0 + my_r; nb < n1; nb += kU * R) {
-        d2 rm[kU], rn[kU], sg[kU];
+        d2 sg[kU];
         int dst[kU];
+        const d2 rm = rho_m2[h2], rn = rho_n2[h2];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
           const int n = min(nb + u * R, n1 - 1);
           const int w = t_pack[n];
           dst[u] = (nb + u * R < n1 && pk_ir(w) >= 0) ? pk_ir(w) * HP + h2 : -1;
-          rm[u] = rho_m2[pk_pr(w) * HP + h2];
-          rn[u] = rho_n2[pk_pr(w) * HP + h2];
           sg[u] = sig_2[(n - 1) * HP + h2];
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
           if (dst[u] >= 0) {
-            rho_m2[dst[u]] = rm[u] * sg[u];
-            rho_n2[dst[u]] = rn[u];
+            rho_m2[dst[u]] = rm * sg[u];
+            rho_n2[dst[u]] = rn;
           }
       }
     }
@@ -230,22 +238,19 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // leaves: one thread per node, sequential over the hands (the sums below are order-sensitive).  Pseudo-leaves are taken
     // from the front of the block, terminals from its back: different waves, so the two paths run side by side instead of
     // one after the other in every wave that holds both kinds
-    const bool times_sigma = mover == opp;  // the opponent acted: its reach at the leaf is the parent's times sigma
-    for (int n = n0 + tid; n < n1; n += NT) {
-      const int lr = t_lrow[n];
-      if (lr < 0) continue;
-      const int pr = pk_pr(t_pack[n]);
-      const double* ro = (times_sigma ? rho_m : rho_n) + pr * H;
-      const double* sg = sig + (n - 1) * H;
+    for (int k = tid; k < L; k += NT) {
+      const int n = t_leaf[k];
+      const int e = opp_edge(n);
+      const double* sg = sig + max(e, 0) * H;
       double s = 0.0;
-      if (times_sigma) {
+      if (e >= 0) {
 #pragma unroll 12
         for (int h = 0; h < H; ++h) s += ro[h] * sg[h];
       } else {
 #pragma unroll 12
         for (int h = 0; h < H; ++h) s += ro[h];
       }
-      lsum[lr] = s;
+      lsum[k] = s;
     }
     RBL_F1();  // pseudo-leaves
     // terminals (:80-98, :765-789): FOUR threads per node -- one per match bin (a hand shows 0..DICE matches) and one for the
@@ -258,10 +263,8 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       const int ln = tid & 63;
       for (int g0 = g; g0 < T; g0 += NT / 4) {
         const int n = t_term[g0];
-        if (n < n0 || n >= n1) continue;  // uniform over the four threads of a group
-        const int pr = pk_pr(t_pack[n]);
-        const double* ro = (times_sigma ? rho_m : rho_n) + pr * H;
-        const double* sg = sig + (n - 1) * H;
+        const int e = opp_edge(n);
+        const double* sg = sig + max(e, 0) * H;
         const int bid = t_act[t_parent[n]];  // the bid that was called is the parent's last bid
         const int qty = 1 + bid / FACES, face = bid % FACES;
         // which hands show exactly 1 / exactly 2 matches of `face`: two 36-bit masks in registers (reading the byte table per
@@ -272,7 +275,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 #pragma unroll 12
         for (int h = 0; h < H; ++h) {
           double r = ro[h];
-          if (times_sigma) r = r * sg[h];
+          if (e >= 0) r = r * sg[h];
           acc += ((mine_mask >> h) & 1) ? r : 0.0;
         }
         // the lane that holds role j of this group: reversed thread order, so role j sits at (ln | 3) - j

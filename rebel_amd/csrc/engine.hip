@@ -195,7 +195,8 @@ void Engine::construct() {
   flat_ok_ = env_int("RBL_CFR_FLAT", 1) != 0 && cfr_flat_supported(g_.H, g_.A, g_.dice, g_.faces);
   for (const ShapeDev& s : tabs_.shapes)
     if (tabs_.cb[s.node_off] == tabs_.ce[s.node_off] || cfr_flat_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces) > 160 * 1024 ||
-        s.N > 511 || s.NI > 255 || s.N - s.L > 255)  // the kernel's packed table words: 9-bit node ids, 8-bit row indices
+        s.N > 511 || s.NI > 255 || s.N - s.L > 255 ||  // the kernel's packed table words: 9-bit node ids, 8-bit row indices
+        s.nlev > 3)                                    // leaves take their reach from the root row: subgames of depth <= 2
       flat_ok_ = false;
   rows_global_lds_ = 0;
   for (const ShapeDev& s : tabs_.shapes) rows_global_lds_ = std::max(rows_global_lds_, gs_lds_bytes(s));
