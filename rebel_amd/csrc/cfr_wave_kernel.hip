@@ -125,8 +125,9 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   RBL_STAMP();  // 0
 
   // ---------------------------------------------------------------- stage: every global load in flight before the first store.
-  // Loads and LDS stores are UNCONDITIONAL, at compile-time offsets from one per-thread base (no clamps, no exec-mask
-  // branches -- they were a third of this kernel's scalar instructions): the engine pads every global array these loads
+  // Loads and LDS stores are UNCONDITIONAL, at compile-time offsets from one per-thread base (no exec-mask branches -- they
+  // were a third of this kernel's scalar instructions -- and clamps only on the strides that can reach past the lane's own
+  // data: round 3, PMC reads 140.7 -> 109.9 MB per 16 384-lane launch for +0.3 us): the engine pads every global array these loads
   // can overrun (kWavePad), and the LDS stores run front to back through the lane's image -- sigma, root reach rows,
   // leaf values, the byte tables in layout order -- so whatever a too-long store spills into the following arrays is
   // overwritten by the stores that own them (the LDS pipeline keeps a wave's stores in order); the image is allocated
@@ -137,15 +138,19 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   constexpr int KL = (LHM / H + W - 1) / W;
   float lv_[KL][H];
   {
-    const float* gv = a.values + ((size_t)row_off + tid) * H;
+    const float* gv = a.values + (size_t)row_off * H;
     // one wave-uniform choice of how many 64-row strides the lane's L rows need (a test per stride would serialise the
-    // loads; always loading the maximum made small trees read their neighbours' rows: 1.9x fabric traffic)
+    // loads; always loading the maximum made small trees read their neighbours' rows: 1.9x fabric traffic).  Within a stride
+    // the row index is CLAMPED to the lane's last row: threads past it re-read that row (a cache hit) instead of the next
+    // lanes' rows, which live in other XCDs' L2 slices and came over the fabric a second time.
     auto load_lv = [&](auto kc) {
       constexpr int K = decltype(kc)::value;
 #pragma unroll
-      for (int u = 0; u < K; ++u)
+      for (int u = 0; u < K; ++u) {  // only the last stride of the choice can reach past the lane's rows
+        const float* gr = gv + (size_t)(u + 1 < K ? tid + u * W : min(tid + u * W, L - 1)) * H;
 #pragma unroll
-        for (int h = 0; h < H; ++h) lv_[u][h] = gv[(size_t)u * W * H + h];
+        for (int h = 0; h < H; ++h) lv_[u][h] = gr[h];
+      }
     };
     if (KL >= 2 && L > W)
       load_lv(std::integral_constant<int, KL>{});
@@ -158,8 +163,10 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     constexpr int KS3 = (KS + 2) / 3, KS23 = (2 * KS + 2) / 3;  // thirds of the stride count, same wave-uniform choice
     auto load_sig = [&](auto kc) {
       constexpr int K = decltype(kc)::value;
+      // clamped to the lane's last element: the tail of the last stride re-reads it instead of the next lane's slab
+      // (only the last third of the chosen stride count can reach past it: the choice is the smallest third that covers EH)
 #pragma unroll
-      for (int u = 0; u < K; ++u) s_[u] = gs0[u * W];
+      for (int u = 0; u < K; ++u) s_[u] = u < K - KS3 ? gs0[u * W] : g_sig[min(tid + u * W, EH - 1)];
     };
     const int sig_strides = EH <= KS3 * W ? KS3 : (EH <= KS23 * W ? KS23 : KS);
     if (sig_strides == KS3)
