@@ -14,7 +14,10 @@ lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
-                measured live with HIP events on the engine stream over the timed region (every 8th iteration).  At the
+                measured live with HIP events on the engine stream over the timed region (every 7th iteration: an ODD
+                stride, so both traversers are sampled -- the subgame roots of depth-2 self-play always belong to player 0,
+                and a CFR step whose traverser owns the root level touches a fifth of the edges the other one does;
+                until round 3 the stride was 8, i.e. only the cheap steps were timed and counted).  At the
                 default 16 384 lanes the engine runs ONE stream -- net(all lanes) -> cfr(all lanes) per iteration -- so a
                 kernel has the GPU to itself and the durations are its own; below 16 384 lanes it interleaves two half-
                 batches on two streams ("in-mix" durations) and `standalone` then carries the one-stream figures of a
@@ -143,7 +146,7 @@ def main():
         eng.close()
         return dt, units, games, n_ex, st, on_device
 
-    dt, units, games, n_examples, st, walk_on_device = run_leg(a.lanes, a.warmup, a.steps, 8, True)
+    dt, units, games, n_examples, st, walk_on_device = run_leg(a.lanes, a.warmup, a.steps, 7, True)
 
     dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
                                               float(games)) if use_dist else (dt, float(units), float(games))
@@ -161,7 +164,7 @@ def main():
     if world == 1 and not a.no_extra_legs and streams > 1:
         # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
         os.environ["RBL_PARTS"] = "1"
-        sdt, sunits, _, _, sst, _ = run_leg(a.lanes, 1, 2, 4, False)
+        sdt, sunits, _, _, sst, _ = run_leg(a.lanes, 1, 2, 3, False)
         if parts_env:
             os.environ["RBL_PARTS"] = parts_env
         else:
