@@ -218,7 +218,8 @@ typedef struct {
    * no MLP net); number of lane parts = streams of the last batch */
   int32_t cfr_kernel, net_kernel, n_streams, reserved;
 } rbl_kernel_stats;
-/* stride = 0: off; n > 0: bracket the CFR and net launches of every n-th iteration with HIP events */
+/* stride = 0: off; n > 0: bracket the CFR and net launches of every n-th iteration with HIP events.  Use an ODD n: the
+ * traverser of iteration i is i mod 2 and the two traversers' steps differ in cost (an even stride samples one of them only) */
 int rbl_engine_timing(rbl_engine* e, int stride);
 int rbl_engine_stats(rbl_engine* e, rbl_kernel_stats* out, int reset);
 
