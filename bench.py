@@ -2,7 +2,10 @@
 """bench.py -- the headline benchmark: self-play data generation for ReBeL on Liar's Dice, MI355X engine.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+`--gpus N` is honoured either way it is launched: under `python -m torch.distributed.run --nproc-per-node N ...` (the rank
+variables are in the environment; WORLD_SIZE must equal N) or bare -- then bench.py starts the N ranks itself (re-executing
+under torch.distributed.run on 127.0.0.1) and fails loudly when fewer than N GPUs are visible.
 
 Metric (BASELINE.json): subgame CFR iterations/sec, whole job, 1 die x 6 faces @ 1024 iterations per subgame.
 A "step" is one pass of the hot path over one batch: EVERY lane plays one subgame of its self-play game end to end --
@@ -14,23 +17,29 @@ lane sets (seeds rank*lanes+i), no data-path collective: "scaling": "weak".
 
 The JSON line also carries
   roofline      dominant kernel (the fused MLP forward; MFMA-bound): algorithmic FLOP per launch / mean launch duration,
-                measured live with HIP events on the engine stream over the timed region (every 7th iteration: an ODD
-                stride, so both traversers are sampled -- the subgame roots of depth-2 self-play always belong to player 0,
-                and a CFR step whose traverser owns the root level touches a fifth of the edges the other one does;
-                until round 3 the stride was 8, i.e. only the cheap steps were timed and counted).  At the
-                default 16 384 lanes the engine runs ONE stream -- net(all lanes) -> cfr(all lanes) per iteration -- so a
-                kernel has the GPU to itself and the durations are its own; below 16 384 lanes it interleaves two half-
-                batches on two streams ("in-mix" durations) and `standalone` then carries the one-stream figures of a
-                short extra leg
-  roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration, in-mix + standalone
-  traffic       HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json, separate
-                --pmc FETCH_SIZE / WRITE_SIZE runs of this same command; FETCH x2 per the gfx950 note of the guide)
+                measured live over the timed region on every 7th iteration (an ODD stride: both traversers are sampled).
+                Durations are the kernels' own begin -> end intervals: the two HIP events are bound to the dispatch packet
+                (hipExtLaunchKernelGGL; rebel_amd/csrc/launch_timing.h), i.e. the timestamps rocprofv3 --kernel-trace
+                reports, without the launch gap a recorded event pair includes.  At the default 16 384 lanes the engine runs
+                ONE stream -- net(all lanes) -> cfr(all lanes) per iteration -- so a kernel has the GPU to itself; below
+                16 384 lanes it interleaves two half-batches on two streams ("in-mix" durations)
+  roofline_cfr  the CFR step kernel (HBM-bound): algorithmic bytes per launch / mean launch duration
+  traffic       HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
+                --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, which cannot be taken inside a timed run; FETCH x2
+                per the gfx950 note of the guide)
+  configs       the other BASELINE.json configurations on the same engine (N = 1 only): 1dx4f @1024 x 4 096 lanes, 2dx3f
+                @1024 x 16 384 lanes, 2dx6f @2048 x 2 048 lanes -- value, ms_per_step, both kernels' roofline fractions
+                and the reference path's rate on this box's host cores
+  per_gpu       (N > 1) every rank's own rate and roofline fractions, and the ranks the RCCL process group saw
   cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so) timed on this box's host cores for >= 30 s per
                 generator-thread count in {16, 32, 60 (README), os.cpu_count()} -- a reported baseline, not a target.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import socket
 import subprocess
 import sys
 import time
@@ -42,10 +51,14 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense f
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: f32-input MFMA peak (= f32 vector peak), quoted for context
 HBM_PEAK_GBPS = 8000.0         # same guide: HBM3E spec peak
 
+# BASELINE.json configs[1], [3], [4] as single-GPU legs of the `configs` block (configs[2] is the headline, configs[0] the
+# reference's own CPU plumbing case): (index, dice, faces, subgame_iters, lanes)
+OTHER_CONFIGS = [(1, 1, 4, 1024, 4096), (3, 2, 3, 1024, 16384), (4, 2, 6, 2048, 2048)]
 
-def cpu_baseline(dice, faces, iters, seconds):
+
+def cpu_baseline(dice, faces, iters, seconds, threads=0):
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--dice", str(dice), "--faces", str(faces),
-           "--iters", str(iters), "--seconds", str(seconds)]
+           "--iters", str(iters), "--seconds", str(seconds), "--threads", str(threads)]
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=seconds + 240)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -59,13 +72,72 @@ def cpu_baseline(dice, faces, iters, seconds):
         port = orc.Oracle("port")
         p = orc.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
         t0, games, subgames = time.time(), 0, 0.0
-        while time.time() - t0 < seconds:
+        while time.time() - t0 < min(seconds, 20):
             subgames += len(port.rl_run(dice, faces, p, games, 1, net=orc.NET_SYNTHETIC)) / 2
             games += 1
         return {"value": subgames * iters / (time.time() - t0), "unit": "subgame-CFR-iterations/s", "cores": 1,
                 "host_cores": os.cpu_count(), "kind": "port",
                 "sample": f"reference build unavailable ({ex}); port oracle, 1 thread, {games} games, elementwise "
                           f"synthetic net instead of Net2 (so this OVERSTATES the CPU path)"}
+
+
+def spawn_ranks(n_gpus):
+    """`--gpus N` without a rank environment: start the N ranks ourselves, one process per GPU (torch.distributed.run)."""
+    import torch
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n_gpus:
+        sys.stderr.write(f"bench.py: --gpus {n_gpus} was asked for but {have} GPU(s) are visible on this box; refusing to "
+                         f"measure fewer GPUs than the line would claim (n_gpus)\n")
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1")))
+
+
+def rocprof_timed_epochs(kernel_key, steps_warmup):
+    """Per-launch duration of `kernel_key` over the timed epochs of the newest committed rocprofv3 --kernel-trace run of this
+    command (scripts/collect_profiles.sh -> profiles/rNN_kernel_stats_timed_epochs.csv), if it has this run's steps / warm-up."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats_timed_epochs.csv")), reverse=True):
+        tag = os.path.basename(path).split("_")[0]
+        try:
+            meta = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
+            if meta.get("steps_warmup") != list(steps_warmup):
+                continue
+            for row in csv.DictReader(open(path)):
+                if any(k in row["kernel"] for k in kernel_key):
+                    return {"avg_launch_us": float(row["avg_ns_timed_epochs"]) / 1e3, "launches": int(row["launches_timed_epochs"]),
+                            "kernel": row["kernel"], "lanes_profiled": meta.get("lanes"),
+                            "source": os.path.relpath(path, ROOT)}
+        except Exception:
+            continue
+    return None
+
+
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of `kernel_key` from the newest committed PMC summary (scripts/collect_profiles.sh)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for name, k in d.get("kernels", {}).items():
+            if any(key in name for key in kernel_key) and "fetch_size_bytes_per_launch" in k and \
+                    "write_size_bytes_per_launch" in k:
+                # mean over the launches of the profiled run's TIMED epochs where the summary has it (same command
+                # shape as this run: same lanes, seeds, warm-up), else the median over all launches
+                rd, wr = (x.get("timed_epochs", {}).get("mean", x["median"]) for x in
+                          (k["fetch_size_bytes_per_launch"], k["write_size_bytes_per_launch"]))
+                return {"bytes": rd + wr, "read": rd, "written": wr,
+                        "restricted_to_timed_epochs": "timed_epochs" in k["fetch_size_bytes_per_launch"],
+                        "profiled_steps_warmup": d.get("steps_warmup"),
+                        "source": os.path.relpath(path, ROOT), "kernel": name,
+                        "lanes_profiled": d.get("lanes"), "note": d.get("note")}
+    return None
 
 
 def main():
@@ -79,22 +151,36 @@ def main():
     ap.add_argument("--faces", type=int, default=6)
     ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("BENCH_CPU_SECONDS", 120)),
                     help="total CPU-baseline window, split over the generator-thread counts (>= 30 s each by default)")
+    ap.add_argument("--config-cpu-seconds", type=float, default=float(os.environ.get("BENCH_CONFIG_CPU_SECONDS", 15)),
+                    help="reference-path window per entry of the `configs` block (at the headline's best thread count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
-                    help="skip the stand-alone kernel leg and the 4096-lane comparison leg (profiling runs)")
+                    help="skip the comparison legs and the `configs` block (profiling runs)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block only")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or without a "
+                         f"rank environment, then bench.py starts the ranks itself)\n")
+        sys.exit(2)
 
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch  # first: librebel_hip.so then binds to the HIP runtime torch already loaded (same SONAME)
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: rebel_amd has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise RuntimeError(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or a.force_dist
     if use_dist:
@@ -104,22 +190,24 @@ def main():
 
     from rebel_amd import capi
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
-    from rebel_amd.sharding import lane_seeds, reduce_job
-
-    torch.manual_seed(0)  # same random-init net on every rank (weights are read-only shared state)
-    net = Net2(num_faces=a.faces, num_dice=a.dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
-    params = capi.make_params(num_iters=a.iters, max_depth=2, linear_update=True, use_cfr=True)
-    weights = mlp_weights_from_state_dict(net.state_dict())
+    from rebel_amd.sharding import gather_ranks, lane_seeds, reduce_job
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_leg(lanes, warmup, steps, timing_stride, sync_ranks):
+    def make_net(dice, faces):
+        torch.manual_seed(0)  # same random-init net on every rank (weights are read-only shared state)
+        net = Net2(num_faces=faces, num_dice=dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+        return mlp_weights_from_state_dict(net.state_dict())
+
+    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks):
         """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
-        eng = capi.Engine(a.dice, a.faces, params, max_lanes=lanes, device=local_rank)
-        eng.set_net_mlp(*weights)
+        dice, faces, iters = game
+        params = capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
+        eng = capi.Engine(dice, faces, params, max_lanes=lanes, device=local_rank)
+        eng.set_net_mlp(*make_net(dice, faces))
         sp = capi.SelfPlay(eng, lane_seeds(rank, lanes), random_action_prob=0.25, sample_leaf=True)
         for _ in range(warmup):
             sp.advance(collect=False)
@@ -146,11 +234,6 @@ def main():
         eng.close()
         return dt, units, games, n_ex, st, on_device
 
-    dt, units, games, n_examples, st, walk_on_device = run_leg(a.lanes, a.warmup, a.steps, 7, True)
-
-    dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
-                                              float(games)) if use_dist else (dt, float(units), float(games))
-
     def kernel_figures(st):
         net_t = st["net_ms"] / max(1, st["net_launches"]) * 1e-3
         cfr_t = st["cfr_ms"] / max(1, st["cfr_launches"]) * 1e-3
@@ -158,67 +241,72 @@ def main():
         cfr_gb = st["cfr_bytes"] / max(1, st["cfr_launches"]) / cfr_t / 1e9 if cfr_t > 0 else 0.0
         return net_t, cfr_t, net_tf, cfr_gb
 
-    standalone = lanes4096 = None
+    headline = (a.dice, a.faces, a.iters)
+    dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True)
+    net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
+
+    dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
+                                              float(games)) if use_dist else (dt, float(units), float(games))
+    per_rank = gather_ranks(dist, world, [float(rank), float(local_rank), units / dt, dt, net_tf / MFMA_F16_PEAK_TFLOPS,
+                                          cfr_gb / HBM_PEAK_GBPS, cfr_gb, net_t * 1e6, cfr_t * 1e6]) if use_dist else None
+
+    two_streams = lanes4096 = None
     parts_env = os.environ.get("RBL_PARTS")
     streams = int(st["n_streams"])  # what the engine ran (rbl_engine_stats), not what the environment suggests
-    if world == 1 and not a.no_extra_legs and streams > 1:
-        # the same kernels with the GPU to themselves: one stream, the launches of an iteration back to back
-        os.environ["RBL_PARTS"] = "1"
-        sdt, sunits, _, _, sst, _ = run_leg(a.lanes, 1, 2, 3, False)
-        if parts_env:
-            os.environ["RBL_PARTS"] = parts_env
-        else:
-            del os.environ["RBL_PARTS"]
-        s_net_t, s_cfr_t, s_net_tf, s_cfr_gb = kernel_figures(sst)
-        standalone = {"net": {"avg_launch_us": s_net_t * 1e6, "rows_per_launch": sst["net_rows"] / max(1, sst["net_launches"]),
-                              "achieved": s_net_tf, "frac": s_net_tf / MFMA_F16_PEAK_TFLOPS,
-                              "ns_per_row": s_net_t * 1e9 / max(1.0, sst["net_rows"] / max(1, sst["net_launches"]))},
-                      "cfr": {"avg_launch_us": s_cfr_t * 1e6, "achieved": s_cfr_gb, "frac": s_cfr_gb / HBM_PEAK_GBPS},
-                      "value_serial": sunits / sdt,
-                      "note": "RBL_PARTS=1: one stream, net(all lanes) -> cfr(all lanes) per iteration; 1 warm-up + 2 timed "
-                              "epochs from the root state (root-heavy mix: more rows per lane than the steady state)"}
-    two_streams = None
     if world == 1 and not a.no_extra_legs and streams == 1 and not parts_env:
         # what two interleaved half-batches would give at this lane count (kernel tails overlap; per-kernel timings are
         # then contended, which is why the headline leg runs one stream)
         os.environ["RBL_PARTS"] = "2"
-        tdt, tunits, _, _, _, _ = run_leg(a.lanes, a.warmup, a.steps, 0, False)
+        tdt, tunits, _, _, _, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 0, False)
         del os.environ["RBL_PARTS"]
         two_streams = {"value": tunits / tdt, "note": "RBL_PARTS=2, same warm-up and timed epochs as the headline leg"}
-    if world == 1 and not a.no_extra_legs:
-        if a.lanes != 4096:
-            ldt, lunits, _, _, _, _ = run_leg(4096, a.warmup, a.steps, 0, False)
-            lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
-                         "streams), same warm-up and timed epochs as the headline leg"}
+    if world == 1 and not a.no_extra_legs and a.lanes != 4096:
+        ldt, lunits, _, _, _, _ = run_leg(headline, 4096, a.warmup, a.steps, 0, False)
+        lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
+                     "streams), same warm-up and timed epochs as the headline leg"}
 
-    def pmc_traffic(kernel_key):
-        """HBM-side bytes per launch of `kernel_key` from the newest committed PMC summary (scripts/collect_profiles.sh)."""
-        import glob
-
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            try:
-                d = json.load(open(path))
-            except Exception:
-                continue
-            for name, k in d.get("kernels", {}).items():
-                if any(key in name for key in kernel_key) and "fetch_size_bytes_per_launch" in k and \
-                        "write_size_bytes_per_launch" in k:
-                    # mean over the launches of the profiled run's TIMED epochs where the summary has it (same command
-                    # shape as this run: same lanes, seeds, warm-up), else the median over all launches
-                    rd, wr = (x.get("timed_epochs", {}).get("mean", x["median"]) for x in
-                              (k["fetch_size_bytes_per_launch"], k["write_size_bytes_per_launch"]))
-                    return {"bytes": rd + wr, "read": rd, "written": wr,
-                            "restricted_to_timed_epochs": "timed_epochs" in k["fetch_size_bytes_per_launch"],
-                            "profiled_steps_warmup": d.get("steps_warmup"),
-                            "source": os.path.relpath(path, ROOT), "kernel": name,
-                            "lanes_profiled": d.get("lanes"), "note": d.get("note")}
-        return None
-
-    if rank == 0:
-        net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
-        H_, A_ = a.faces ** a.dice, 2 * a.dice * a.faces + 1
+    def roofline_blocks(game, st, streams_):
+        """The `roofline` / `roofline_cfr` objects of one leg from its kernel stats."""
+        dice, faces, _ = game
+        n_t, c_t, n_tf, c_gb = kernel_figures(st)
+        H_, A_ = faces ** dice, 2 * dice * faces + 1
         Q_ = 2 + A_ + 2 * H_
         issued_ratio = 3.0 * (-(-Q_ // 32) * 32 * 256 + 256 * 256 + 256 * -(-H_ // 16) * 16) / (Q_ * 256 + 256 * 256 + 256 * H_)
+        how = "HIP events bound to the dispatch packet (hipExtLaunchKernelGGL): the kernel's own begin -> end interval, as " \
+              "rocprofv3 --kernel-trace reports it; "
+        how += "one stream, net(all lanes) -> cfr(all lanes) per iteration: the kernel has the GPU to itself" if streams_ == 1 \
+            else "in-mix: the other stream's kernel is active beside it"
+        rows = st["net_rows"] / max(1, st["net_launches"])
+        net = {"kernel": capi.NET_KERNEL_NAMES.get(st["net_kernel"], str(st["net_kernel"])), "bound": "mfma", "achieved": n_tf,
+               "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": n_tf / MFMA_F16_PEAK_TFLOPS, "traffic": None,
+               "avg_launch_us": n_t * 1e6, "timed_launches": st["net_launches"], "rows_per_launch": rows,
+               "ns_per_row": n_t * 1e9 / max(1.0, rows),
+               "algorithmic_flops_per_launch": st["net_flops"] / max(1, st["net_launches"]), "measured": how,
+               "issued_mfma_tflops": n_tf * issued_ratio, "vs_f32_mfma_peak": n_tf / MFMA_F32_PEAK_TFLOPS}
+        cfr = {"kernel": capi.CFR_KERNEL_NAMES.get(st["cfr_kernel"], str(st["cfr_kernel"])), "bound": "hbm", "achieved": c_gb,
+               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": c_gb / HBM_PEAK_GBPS, "traffic": None,
+               "avg_launch_us": c_t * 1e6, "timed_launches": st["cfr_launches"],
+               "algorithmic_bytes_per_launch": st["cfr_bytes"] / max(1, st["cfr_launches"]),
+               "measured": how + ("" if st["cfr_kernel"] != 4 else "; this kernel is launched once per size-sorted segment of the "
+                                  "lanes, so a step is bracketed with recorded events (launch gaps between the segments included)")}
+        return net, cfr
+
+    configs = []
+    if world == 1 and not a.no_extra_legs and not a.no_configs and headline == (1, 6, 1024):
+        # the other BASELINE.json configurations on this engine, one GPU; short legs (3 warm-up + 5 timed epochs)
+        for idx, d_, f_, it_, ln_ in OTHER_CONFIGS:
+            cw, cs = min(3, max(1, a.warmup)), min(5, max(2, a.steps))
+            cdt, cunits, cgames, _, cst, _ = run_leg((d_, f_, it_), ln_, cw, cs, 7, False)
+            cnet, ccfr = roofline_blocks((d_, f_, it_), cst, int(cst["n_streams"]))
+            keep = ("kernel", "achieved", "unit", "frac", "avg_launch_us", "timed_launches")
+            configs.append({"baseline_config": idx, "workload": f"{d_}dx{f_}f self-play, {ln_} lanes, subgame_iters={it_}, depth 2",
+                            "value": cunits / cdt, "unit": "subgame-CFR-iterations/s", "ms_per_step": cdt / cs * 1e3,
+                            "steps": cs, "warmup": cw, "games_per_s": cgames / cdt, "streams": int(cst["n_streams"]),
+                            "net": {k: cnet[k] for k in keep + ("rows_per_launch", "ns_per_row")},
+                            "cfr": {k: ccfr[k] for k in keep + ("algorithmic_bytes_per_launch",)}})
+
+    if rank == 0:
+        rl_net, rl_cfr = roofline_blocks(headline, st, streams)
         out = {
             "metric": "subgame CFR iters/sec (whole job), 1dx6f @1024 iters; self-play games/sec in games_per_s",
             "value": units_all / dt_max,
@@ -245,38 +333,34 @@ def main():
             # 3 f16 MFMA products per multiply on padded tiles (K 27->32, H 6->16): 3.16x this on the matrix pipe.  On
             # gfx950 the f16 MFMA pipe and f32 FMA-class VALU work do not overlap (scripts/micro/), and the LayerNorm +
             # erf-GELU epilogue on 512 activations per row costs about as many issue cycles as the MFMAs: see DESIGN.md
-            "roofline": {"kernel": capi.NET_KERNEL_NAMES.get(st["net_kernel"], str(st["net_kernel"])), "bound": "mfma", "achieved": net_tf,
-                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": net_tf / MFMA_F16_PEAK_TFLOPS,
-                         "traffic": None, "avg_launch_us": net_t * 1e6, "timed_launches": st["net_launches"],
-                         "rows_per_launch": st["net_rows"] / max(1, st["net_launches"]),
-                         "ns_per_row": net_t * 1e9 / max(1.0, st["net_rows"] / max(1, st["net_launches"])),
-                         "algorithmic_flops_per_launch": st["net_flops"] / max(1, st["net_launches"]),
-                         "measured": ("HIP events on the engine stream; one stream, net(all lanes) -> cfr(all lanes) per iteration: "
-                                      "the kernel has the GPU to itself") if streams == 1 else
-                                     "in-mix: HIP events on the launch's own stream, the other stream's CFR kernel active",
-                         "issued_mfma_tflops": net_tf * issued_ratio,
-                         "vs_f32_mfma_peak": net_tf / MFMA_F32_PEAK_TFLOPS},
-            "roofline_cfr": {"kernel": capi.CFR_KERNEL_NAMES.get(st["cfr_kernel"], str(st["cfr_kernel"])), "bound": "hbm",
-                             "achieved": cfr_gb, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": cfr_gb / HBM_PEAK_GBPS, "traffic": None,
-                             "avg_launch_us": cfr_t * 1e6, "timed_launches": st["cfr_launches"],
-                             "algorithmic_bytes_per_launch": st["cfr_bytes"] / max(1, st["cfr_launches"]),
-                             "measured": "HIP events on the engine stream; the kernel has the GPU to itself" if streams == 1 else
-                                         "in-mix: HIP events on the launch's own stream, the other stream's net kernel active"},
+            "roofline": rl_net,
+            "roofline_cfr": rl_cfr,
             "streams": streams,
             "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
         }
-        for key, kern in (("roofline", ("mlp_resident_kernel", "mlp_pipe_kernel")), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
+        for key, kern in (("roofline", ("mlp_resident_kernel",)), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
             # the committed PMC passes were taken on the headline configuration: other games report traffic = null
-            tr = pmc_traffic(kern) if (a.dice, a.faces, a.iters) == (1, 6, 1024) else None
+            tr = pmc_traffic(kern) if headline == (1, 6, 1024) else None
             if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
                 scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0
                 out[key]["traffic"] = tr["bytes"] * scale
                 out[key]["traffic_detail"] = tr
-        if standalone:
-            out["roofline"]["standalone"] = standalone["net"]
-            out["roofline_cfr"]["standalone"] = standalone["cfr"]
-            out["standalone_leg"] = {k: standalone[k] for k in ("value_serial", "note")}
+                out[key]["traffic_measured"] = ("NOT in this run: counter passes serialise the kernels, so they are a separate, "
+                                                "committed rocprofv3 --pmc run of this same command (source in traffic_detail)")
+            rp = rocprof_timed_epochs(kern, (a.steps, a.warmup)) if headline == (1, 6, 1024) else None
+            if rp and rp.get("lanes_profiled") == a.lanes:
+                # the same launches (same seeds, lanes, warm-up, timed epochs) as seen by rocprofv3 in the committed profile: the
+                # algorithmic work per launch is identical, so frac follows from that run's duration
+                work = out[key]["algorithmic_flops_per_launch"] / 1e12 if key == "roofline" else \
+                    out[key]["algorithmic_bytes_per_launch"] / 1e9
+                rp["achieved"] = work / (rp["avg_launch_us"] * 1e-6)
+                rp["frac"] = rp["achieved"] / out[key]["peak"]
+                out[key]["rocprof"] = rp
+        if per_rank:
+            out["per_gpu"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
+                              "ranks": [{"rank": int(r[0]), "gpu": int(r[1]), "value": r[2], "seconds": r[3], "net_frac_mfma": r[4],
+                                         "cfr_frac_hbm": r[5], "cfr_gbps": r[6], "net_launch_us": r[7], "cfr_launch_us": r[8]}
+                                        for r in per_rank]}
         if lanes4096:
             out["lanes_4096"] = lanes4096
         if two_streams:
@@ -285,6 +369,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
             if out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            best_threads = out["cpu_baseline"].get("cores", 16) if out["cpu_baseline"].get("kind") == "reference" else 16
+            for c in configs:  # the reference path on the same configuration, at the headline's best generator-thread count
+                d_, f_, it_ = next((d, f, it) for i, d, f, it, _ in OTHER_CONFIGS if i == c["baseline_config"])
+                c["cpu_reference"] = cpu_baseline(d_, f_, it_, a.config_cpu_seconds, threads=best_threads)
+                if c["cpu_reference"].get("value"):
+                    c["speedup_vs_cpu_reference"] = c["value"] / c["cpu_reference"]["value"]
+        if configs:
+            out["configs"] = configs
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -137,6 +137,24 @@ int rbl_strategy_recursive_sampled(rbl_engine* e, int seed, int root_only, doubl
  * the two sweeps, bytes of the device-resident strategy, frontier items followed, M. */
 int rbl_exploitability_recursive(rbl_engine* e, int shard, int n_shards, double out[2], double* top_values,
                                  int32_t* top_owner, double* stats);
+/* The same with the dealt level chosen by the caller.  deal_levels = K >= 1: the frontier PRODUCED by recursion level K - 1
+ * (the non-terminal nodes at depth K * max_depth) is dealt to the shards, largest subtree first; the K levels above are
+ * solved by every shard.  K = 1 is rbl_exploitability_recursive: a depth-max_depth subtree can be a quarter of the game
+ * (2 dice x 6 faces: 8 shards -> 3.7x).  K = 2: every shard redundantly solves the root subgame and its depth-max_depth
+ * subgames (277 of 8.4 M at 2 dice x 6 faces), the largest dealt subtree is 1/16 of the game and 8 shards balance.
+ * M = rbl_exploitability_top_nodes(dice, faces, max_depth, K) = nodes of depth <= K * max_depth sizes top_values [2][M][H]
+ * and top_owner [M].  The shards are independent processes / GPUs; nothing is exchanged between them on the device
+ * (recursive_solving.cc:76-134 recursion order is irrelevant to the result: subgames of a level are independent). */
+int rbl_exploitability_recursive_deal(rbl_engine* e, int shard, int n_shards, int deal_levels, double out[2],
+                                      double* top_values, int32_t* top_owner, double* stats);
+int64_t rbl_exploitability_top_nodes(int dice, int faces, int max_depth, int deal_levels); /* -1: error */
+/* Shards -> compute_exploitability2's two numbers (subgame_solving.cc:802-816), on the host: BRSolver::compute_br
+ * (:326-355) over the top M nodes, every dealt node's value taken from its owner (top_values[owner]), everything else from
+ * shard 0; maximum = first child then strictly greater, opponent sums ascending, vector_sum / H.  top_values: n_shards
+ * pointers to the shards' [2][M][H] arrays; top_owner: any shard's [M] map (they are identical).  Bit-identical to the
+ * unsharded out[2]. */
+int rbl_exploitability_combine(int dice, int faces, int max_depth, int deal_levels, int n_shards,
+                               const double* const* top_values, const int32_t* top_owner, double out[2]);
 /* compute_immediate_regrets (subgame_solving.cc:984-1050; printed by recursive_eval --print_regret[_summary],
  * recursive_eval.cc:28-53): strategies = n_strategies dense full-tree strategies [N_full][H][A] back to back; out[N_full][H] =
  * max over the actions of the regret accumulated over all strategies and both traversers, divided by n_strategies (0 on
@@ -214,7 +232,8 @@ typedef struct {
   double cfr_bytes, net_flops;        /* algorithmic bytes / flops of the timed launches (per-lane shapes) */
   /* what the engine actually launched last (reporting; not reset): CFR step kernel 0 generic (cfr_step_kernel), 1 one
    * thread per tree row (cfr_rows_kernel), 2 one wavefront per lane (cfr_wave_kernel), 3 rows kernel with global state
-   * (2 dice x 6 faces); value-net kernel variant (MlpDev::tile: 6 pipelined, 5 register-resident, 3 feature split; 0 =
+   * (2 dice x 6 faces, RBL_CFR_FLAT=0), 4 element-parallel kernel with sigma in LDS (cfr_flat_kernel, 2 dice x 6 faces);
+   * value-net kernel variant (MlpDev::tile: 6 pipelined, 5 register-resident, 3 feature split; 0 =
    * no MLP net); number of lane parts = streams of the last batch */
   int32_t cfr_kernel, net_kernel, n_streams, reserved;
 } rbl_kernel_stats;

@@ -27,7 +27,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_exploitability_recursive_deal", "rbl_exploitability_top_nodes", "rbl_exploitability_combine", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -132,6 +132,9 @@ def lib():
         "rbl_solver_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_net_debug_stamps": (C.c_int, [vp, C.POINTER(C.c_longlong)]),
         "rbl_exploitability_recursive": (C.c_int, [vp, C.c_int, C.c_int, dp, dp, i32p, dp]),
+        "rbl_exploitability_recursive_deal": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, dp, dp, i32p, dp]),
+        "rbl_exploitability_top_nodes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+        "rbl_exploitability_combine": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(dp), i32p, dp]),
         "rbl_stream_create": (vp, [C.c_int, C.c_int, C.c_int, C.POINTER(Params)]),
         "rbl_stream_destroy": (None, [vp]),
         "rbl_stream_num_nodes": (C.c_int64, [vp]),
@@ -208,32 +211,22 @@ def ev2(dice, faces, strategy1, strategy2, device=0):
     return out
 
 
-def combine_exploitability(dice, faces, max_depth, tops):
-    """Shards of rbl_exploitability_recursive -> the two exploitabilities.  tops[s] = (top_values, top_owner) of shard s.
-    BRSolver::compute_br (subgame_solving.cc:326-355) over the nodes of depth <= max_depth on the host: a non-terminal node
-    at depth max_depth takes its value from the shard that owns its subtree, a terminal from shard 0 (it depends on the
-    root subgame only, which every shard solves); above, the traverser's nodes take the first-then-strictly-greater
-    maximum over their children, the opponent's the sum in ascending order; then vector_sum / H (:813-814)."""
-    tree = unroll_tree(dice, faces, -1, 0, max_depth)
-    owner = tops[0][1]
-    H = tops[0][0].shape[2]
+def combine_exploitability(dice, faces, max_depth, tops, deal_levels=1):
+    """Shards of rbl_exploitability_recursive[_deal] -> the two exploitabilities: rbl_exploitability_combine (host code of the
+    C ABI; BRSolver::compute_br, subgame_solving.cc:326-355, over the nodes of depth <= deal_levels * max_depth with every
+    dealt node's value taken from its owner).  tops[s] = (top_values, top_owner) of shard s."""
+    L = lib()
+    vals = [np.ascontiguousarray(t[0], np.float64) for t in tops]
+    owner = np.ascontiguousarray(tops[0][1], np.int32)
+    M = L.rbl_exploitability_top_nodes(dice, faces, max_depth, deal_levels)
+    if M < 0:
+        raise RebelError(L.rbl_last_error().decode())
+    if any(v.shape[:2] != (2, M) for v in vals) or owner.shape != (M,):
+        raise ValueError(f"combine_exploitability: top arrays must be [2][{M}][H] / [{M}]")
+    ptrs = (C.POINTER(C.c_double) * len(vals))(*[_p(v, C.c_double) for v in vals])
     out = np.zeros(2)
-    for t in range(2):
-        val = np.array(tops[0][0][t], dtype=np.float64, copy=True)
-        for n in range(len(tree) - 1, -1, -1):
-            last_bid, player, cb, ce = (int(x) for x in tree[n][:4])
-            if cb == ce:
-                if owner[n] >= 0:
-                    val[n] = tops[owner[n]][0][t][n]
-                continue
-            v = val[cb].copy()
-            for c in range(cb + 1, ce):
-                v = np.where(val[c] > v, val[c], v) if player == t else v + val[c]
-            val[n] = v
-        s = 0.0
-        for x in val[0]:
-            s += x
-        out[t] = s / H
+    _check(L.rbl_exploitability_combine(dice, faces, max_depth, deal_levels, len(vals), ptrs, _p(owner, C.c_int32),
+                                        _p(out, C.c_double)))
     return out
 
 
@@ -387,18 +380,21 @@ class Engine:
         _check(self.L.rbl_strategy_recursive_sampled(self.h, int(seed), int(root_only), _p(out, C.c_double)))
         return out
 
-    def exploitability_recursive(self, shard=0, n_shards=1, max_depth=None):
-        """rbl_exploitability_recursive: (exploitabilities[2], (top_values[2][M][H], top_owner[M]), stats dict); the
-        full-tree strategy never leaves the device.  max_depth = the engine's params.max_depth (sizes the top levels)."""
+    def exploitability_recursive(self, shard=0, n_shards=1, max_depth=None, deal_levels=1):
+        """rbl_exploitability_recursive_deal: (exploitabilities[2], (top_values[2][M][H], top_owner[M]), stats dict); the
+        full-tree strategy never leaves the device.  max_depth = the engine's params.max_depth (sizes the top levels);
+        deal_levels: which recursion level's frontier the shards share out (include/rebel_hip.h)."""
         if max_depth is None:
             max_depth = self.params.max_depth
-        M = len(unroll_tree(self.dice, self.faces, -1, 0, max_depth))
+        M = self.L.rbl_exploitability_top_nodes(self.dice, self.faces, max_depth, deal_levels)
+        if M < 0:
+            raise RebelError(self.L.rbl_last_error().decode())
         out = np.zeros(2)
         tv = np.zeros((2, M, self.H))
         own = np.full(M, -1, np.int32)
         st = np.zeros(8)
-        _check(self.L.rbl_exploitability_recursive(self.h, int(shard), int(n_shards), _p(out, C.c_double),
-                                                   _p(tv, C.c_double), _p(own, C.c_int32), _p(st, C.c_double)))
+        _check(self.L.rbl_exploitability_recursive_deal(self.h, int(shard), int(n_shards), int(deal_levels), _p(out, C.c_double),
+                                                        _p(tv, C.c_double), _p(own, C.c_int32), _p(st, C.c_double)))
         keys = ("nodes", "subgames", "levels", "solve_s", "sweep_s", "strategy_bytes", "frontier_items", "top_nodes")
         return out, (tv, own), dict(zip(keys, st))
 

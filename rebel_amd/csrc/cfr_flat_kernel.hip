@@ -37,6 +37,7 @@
 #include <string>
 
 #include "cfr_kernels.h"
+#include "launch_timing.h"
 
 namespace rbl {
 
@@ -628,7 +629,7 @@ bool launch_cfr_flat(const CfrArgs& a, int B, size_t lds_bytes, int threads, hip
   });
   if (attr_err != hipSuccess)
     throw std::runtime_error(std::string("cfr_flat: cannot request 160 KB of LDS: ") + hipGetErrorString(attr_err));
-  hipLaunchKernelGGL(kern, dim3(B), dim3(threads), lds_bytes, stream, a);
+  RBL_LAUNCH_TIMED(kern, dim3(B), dim3(threads), lds_bytes, stream, a);
   return true;
 }
 

@@ -20,9 +20,11 @@
 // -ffp-contract=off, explicit fmas only where those kernels have them), so the bit-exactness contract with the reference
 // (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py and tests/test_selfplay_parity.py run against it.
 // Only kModeStep of LDS-resident lanes runs here (RBL_CFR_WAVE=0 switches back to the row kernel).
+#include <algorithm>
 #include <type_traits>
 
 #include "cfr_kernels.h"
+#include "launch_timing.h"
 
 namespace rbl {
 
@@ -30,6 +32,7 @@ namespace {
 
 constexpr double kEps = 1e-80;
 constexpr size_t kWaveLdsSlack = 128;  // bytes behind the lane's LDS image that the unconditional staging stores may touch
+                                       // (cfr_wave_lds_bytes additionally covers the KT*64-dword store of the byte tables)
 
 template <int H>
 struct Row {
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       constexpr int K = decltype(kc)::value;
 #pragma unroll
       for (int u = 0; u < K; ++u) {  // only the last stride of the choice can reach past the lane's rows
-        const float* gr = gv + (size_t)(u + 1 < K ? tid + u * W : min(tid + u * W, L - 1)) * H;
+        const float* gr = gv + (size_t)(u + 1 < K ? tid + u * W : min(tid + u * W, max(L - 1, 0))) * H;  // (L == 0 never gets here; the max keeps the index non-negative regardless)
 #pragma unroll
         for (int h = 0; h < H; ++h) lv_[u][h] = gr[h];
       }
@@ -166,7 +169,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       // clamped to the lane's last element: the tail of the last stride re-reads it instead of the next lane's slab
       // (only the last third of the chosen stride count can reach past it: the choice is the smallest third that covers EH)
 #pragma unroll
-      for (int u = 0; u < K; ++u) s_[u] = u < K - KS3 ? gs0[u * W] : g_sig[min(tid + u * W, EH - 1)];
+      for (int u = 0; u < K; ++u) s_[u] = u < K - KS3 ? gs0[u * W] : g_sig[min(tid + u * W, max(EH - 1, 0))];
     };
     const int sig_strides = EH <= KS3 * W ? KS3 : (EH <= KS23 * W ? KS23 : KS);
     if (sig_strides == KS3)
@@ -526,7 +529,14 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 
 size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
   const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)(NI + 1) * H;  // doubles: sigma, values, reach rows
-  const size_t b = d * 8 + (size_t)(4 * N + L + T) + (size_t)faces * H;
+  size_t b = d * 8 + (size_t)(4 * N + L + T) + (size_t)faces * H;
+  // the byte tables are staged as KT strides of 64 dwords (KT from the instantiation's NM, see launch_cfr_wave) and the
+  // match table as one 64-byte store behind them: the image must hold whichever reaches further (1 die x 5 faces: the
+  // 512-byte table store ends 40 bytes behind the slack of the layout itself)
+  const int NM = H == 4 ? 45 : (H == 5 ? 66 : 91);
+  const size_t KT = (size_t)(((5 * NM + 3) / 4 + 63) / 64);
+  b = std::max(b, d * 8 + KT * 256);
+  b = std::max(b, d * 8 + (size_t)(4 * N + L + T) + 64);
   return ((b + 15) & ~(size_t)15) + kWaveLdsSlack;
 }
 
@@ -542,7 +552,7 @@ bool cfr_wave_supported(int H, int A, int dice, int faces, int max_EH, int max_L
 bool launch_cfr_wave(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream) {
 #define RBL_WAVE(H_, A_, D_, F_, EH_, LH_, N_)                                                                       \
   do {                                                                                                               \
-    hipLaunchKernelGGL((cfr_wave_kernel<H_, A_, D_, F_, EH_, LH_, N_>), dim3(B), dim3(64), lds_bytes, stream, a);    \
+    RBL_LAUNCH_TIMED((cfr_wave_kernel<H_, A_, D_, F_, EH_, LH_, N_>), dim3(B), dim3(64), lds_bytes, stream, a);      \
     return true;                                                                                                     \
   } while (0)
   if (a.H == 6 && a.A == 13 && a.dice == 1) RBL_WAVE(6, 13, 1, 6, 540, 396, 91);

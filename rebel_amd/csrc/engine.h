@@ -157,7 +157,7 @@ class Engine {
   void read_lane(const double* dev_base, int lane, std::vector<double>* out);
   struct Timed;
   void time_begin(int kind, hipStream_t st);
-  void time_end(int kind, hipStream_t st);
+  bool time_end(int kind, hipStream_t st);  // false: the sample was dropped (see launch_timing.h)
 
   int device_;
   Rules g_;
@@ -206,6 +206,8 @@ class Engine {
   int q_ds_ = 0, q_ss_ = 0, mlp_n_in_true_ = 0;
   DevBuf<float> d_qdyn_, d_qstat_, d_tmp_dyn_, d_tmp_stat_;
   void split_part_queries(int part, hipStream_t st);  // canonical rows of a lane part -> dyn / stat rows
+  void leave_split_layout();  // net exchanged mid-solve: rebuild the canonical rows the next net reads (holds net_mutex_)
+  void enter_split_layout();  // ... or the split rows, from the canonical ones
   rbl_net_fn cb_fn_ = nullptr;
   void* cb_user_ = nullptr;
   bool cb_host_ = true;
@@ -253,6 +255,10 @@ class Engine {
     int kind;
     size_t e0, e1;
   };
+  // per kind (0 CFR step, 1 net forward): time through events bound to the dispatch packet (gap-free, what rocprofv3
+  // reports) while the launch is ONE kernel of a launcher that supports it; otherwise bracket with recorded events
+  bool ext_timing_[2] = {true, true};
+  bool ext_armed_ = false;
   std::vector<Pending> pending_;
   size_t ev_used_ = 0;
   rbl_kernel_stats stats_{};
@@ -264,7 +270,10 @@ class Engine {
 // device, edge-indexed (no dense [N][H][A] tabulation); see include/rebel_hip.h: rbl_exploitability_recursive
 Engine& engine_impl(rbl_engine* e);  // the engine behind a C handle (engine.hip)
 void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
-                              double* stats);
+                              double* stats, int deal_levels = 1);
+int64_t exploitability_top_nodes(const Rules& g, int max_depth, int deal_levels);
+void exploitability_combine(const Rules& g, int max_depth, int deal_levels, int n_shards, const double* const* top_values,
+                            const int32_t* top_owner, double* out2);
 
 class SelfPlay {
  public:

@@ -3,6 +3,7 @@
 // few fp64 formulas evaluated here (discounts, root queries, average strategy read-back, Bayes updates while
 // sampling) are part of the bit-exactness contract with the reference.
 #include "engine.h"
+#include "launch_timing.h"
 
 #include <algorithm>
 #include <chrono>
@@ -16,6 +17,8 @@
 #include <thread>
 
 namespace rbl {
+
+thread_local LaunchTimingSlot tl_launch_timing;
 
 namespace {
 
@@ -195,7 +198,7 @@ void Engine::construct() {
   flat_ok_ = env_int("RBL_CFR_FLAT", 1) != 0 && cfr_flat_supported(g_.H, g_.A, g_.dice, g_.faces);
   for (const ShapeDev& s : tabs_.shapes)
     if (tabs_.cb[s.node_off] == tabs_.ce[s.node_off] || cfr_flat_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces) > 160 * 1024 ||
-        s.N > 511 || s.NI > 255 || s.N - s.L > 255 ||  // the kernel's packed table words: 9-bit node ids, 8-bit row indices
+        s.N > 511 || s.NI > 62 || s.N - s.L > 255 ||  // the kernel's packed table words: 9-bit node ids, 8-bit row indices, 6-bit own reach row (pk_ir)
         s.nlev > 3)                                    // leaves take their reach from the root row: subgames of depth <= 2
       flat_ok_ = false;
   rows_global_lds_ = 0;
@@ -213,6 +216,7 @@ void Engine::construct() {
   rows_fit_ = env_int("RBL_CFR_ROWS_FIT", 1) != 0;
   rows_block_ = std::min(128, std::max(64, env_int("RBL_CFR_ROWS_BLOCK", 128)));  // the kernel is built for <= 128 threads
   cfr_dbg_ = env_int("RBL_CFR_DBG", 0) != 0;
+  ext_timing_[0] = ext_timing_[1] = env_int("RBL_TIMING_EXT", 1) != 0;  // 0: bracket with recorded events (includes launch gaps)
   if (cfr_dbg_) {
     d_dbg_.alloc(L * 16);
     RBL_HIP_CHECK(hipMemset(d_dbg_.p, 0, L * 16 * sizeof(long long)));
@@ -255,10 +259,31 @@ void Engine::check_lane(int lane) const {
 }
 
 // ---------------------------------------------------------------------------------------------- value net
+// A net can be exchanged in the middle of a solve (ModelLocker::updateModel, model_locker.h:69-79; tests that reset() before
+// they set the net).  The query layout follows the net kind (split rows for the fused MLP, canonical rows otherwise), so the
+// layout the NEW net reads is rebuilt here from the one the live solve has been writing.  Callers hold net_mutex_.
+void Engine::leave_split_layout() {
+  if (!qsplit_) return;
+  qsplit_ = false;
+  if (rows_ <= 0 || tabs_.max_L == 0 || !q_canon_stale_) return;
+  sync();  // the steps since the last init wrote dynamic rows only: the canonical matrix is rebuilt from them
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  launch_unsplit_queries(d_queries_.p, g_.A, g_.H, d_qdyn_.p, q_ds_, d_qstat_.p, q_ss_, rows_, stream_);
+  RBL_HIP_CHECK(hipGetLastError());
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+  q_canon_stale_ = false;
+}
+
+void Engine::enter_split_layout() {  // canonical rows of a live solve -> (dynamic | static) rows; streams are drained
+  if (rows_ <= 0 || tabs_.max_L == 0) return;
+  for (int part = 0; part < n_parts_; ++part) split_part_queries(part, stream_);
+  RBL_HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
 void Engine::set_net_zero() {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
-  qsplit_ = false;
   RBL_HIP_CHECK(hipSetDevice(device_));
+  leave_split_layout();
   net_mode_ = NetMode::kZero;
   RBL_HIP_CHECK(hipMemsetAsync(d_values_.p, 0, d_values_.n * sizeof(float), stream_));
   values_zeroed_ = true;
@@ -266,7 +291,7 @@ void Engine::set_net_zero() {
 
 void Engine::set_net_synthetic() {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
-  qsplit_ = false;
+  leave_split_layout();
   net_mode_ = NetMode::kSynthetic;
   values_zeroed_ = false;
 }
@@ -274,7 +299,7 @@ void Engine::set_net_synthetic() {
 void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
   if (!fn) throw std::runtime_error("set_net_callback: null function");
-  qsplit_ = false;
+  leave_split_layout();
   net_mode_ = NetMode::kCallback;
   cb_fn_ = fn;
   cb_user_ = user;
@@ -324,6 +349,8 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   mlp_.n_layers = w.n_layers;
   mlp_.n_in = n_in_pack;
   mlp_n_in_true_ = w.n_in;
+  const bool was_split = qsplit_;
+  if (was_split && !(split && pk.tile == 5)) leave_split_layout();
   qsplit_ = split && pk.tile == 5;
   q_ds_ = ds;
   q_ss_ = ss;
@@ -334,8 +361,8 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
     mlp_.q_stat = d_qstat_.p;
     mlp_.q_dyn_stride = ds;
     mlp_.q_stat_stride = ss;
+    if (!was_split) enter_split_layout();  // (a weight refresh of a split net keeps both the rows and q_canon_stale_)
   }
-  q_canon_stale_ = false;
   mlp_.n_hidden = w.n_hidden;
   mlp_.n_out = w.n_out;
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
@@ -434,14 +461,34 @@ void Engine::time_begin(int kind, hipStream_t st) {
     RBL_HIP_CHECK(hipEventCreate(&e));
     ev_pool_.push_back(e);
   }
-  RBL_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_], st));
+  ext_armed_ = ext_timing_[kind];
+  if (ext_armed_) {  // the launcher binds the two events to its dispatch packet (launch_timing.h)
+    tl_launch_timing.start = ev_pool_[ev_used_];
+    tl_launch_timing.stop = ev_pool_[ev_used_ + 1];
+    tl_launch_timing.used = 0;
+  } else {
+    RBL_HIP_CHECK(hipEventRecord(ev_pool_[ev_used_], st));
+  }
   pending_.push_back(Pending{kind, ev_used_, ev_used_ + 1});
   ev_used_ += 2;
 }
 
-void Engine::time_end(int, hipStream_t st) {
-  if (!timed_now()) return;
+bool Engine::time_end(int kind, hipStream_t st) {
+  if (!timed_now()) return false;
+  if (ext_armed_) {
+    const int used = tl_launch_timing.used;
+    tl_launch_timing = LaunchTimingSlot{};
+    ext_armed_ = false;
+    if (used == 1) return true;
+    // none or several kernels took the slot (a launcher without support, segmented launches): this sample has no valid
+    // event pair; from now on this kind is bracketed with recorded events
+    ext_timing_[kind] = false;
+    ev_used_ -= 2;
+    pending_.pop_back();
+    return false;
+  }
   RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], st));
+  return true;
 }
 
 void Engine::stats(rbl_kernel_stats* out, bool reset) {
@@ -785,10 +832,10 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
       if (mode == kModeInit || mode == kModeQueries) split_part_queries(part, st);  // the generic kernel wrote canonical rows
       else if (mode == kModeStep && which == 2) q_canon_stale_ = true;              // the wave kernel wrote dynamic rows only
     }
-    if (is_step) time_end(0, st);
+    const bool sampled = is_step && time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());
     if (is_step) {
-      if (timed_now()) {
+      if (sampled) {
         ++stats_.cfr_launches;
         if (info_dev_)
           ++timed_cfr_[part][trav];  // bytes are added at the end of the epoch (end_epoch_device)
@@ -829,8 +876,7 @@ void Engine::run_net() {
         launch_mlp_forward(m2, d_qdyn_.p + r0 * q_ds_, nr, d_values_.p + r0 * H, st, nullptr);
       }
       RBL_HIP_CHECK(hipGetLastError());
-      if (timed) {
-        time_end(1, st);
+      if (timed && time_end(1, st)) {
         ++stats_.net_launches;
         if (info_dev_) {
           ++timed_net_[part];
@@ -845,16 +891,14 @@ void Engine::run_net() {
     }
     if (info_dev_) {  // rows [part_row[part], part_row[part + 1]) as written by sp_scan; nr is only the launch bound
       net_forward_dev(d_queries_.p, nr, d_values_.p, st, info_dev_->part_row + part);
-      if (timed) {
-        time_end(1, st);
+      if (timed && time_end(1, st)) {
         ++stats_.net_launches;
         ++timed_net_[part];
       }
       continue;
     }
     net_forward_dev(d_queries_.p + r0 * Q, nr, d_values_.p + r0 * H, st);
-    if (timed) {
-      time_end(1, st);
+    if (timed && time_end(1, st)) {
       ++stats_.net_launches;
       stats_.net_rows += nr;
       stats_.net_flops += 2.0 * (double)nr *
@@ -1820,7 +1864,23 @@ int rbl_exploitability2(int device, int dice, int faces, const double* strategy,
 }
 int rbl_exploitability_recursive(rbl_engine* e, int shard, int n_shards, double out[2], double* top_values,
                                  int32_t* top_owner, double* stats) {
-  return guard([&] { rbl::exploitability_recursive(need(e), shard, n_shards, out, top_values, top_owner, stats); });
+  return guard([&] { rbl::exploitability_recursive(need(e), shard, n_shards, out, top_values, top_owner, stats, 1); });
+}
+int rbl_exploitability_recursive_deal(rbl_engine* e, int shard, int n_shards, int deal_levels, double out[2],
+                                      double* top_values, int32_t* top_owner, double* stats) {
+  return guard([&] { rbl::exploitability_recursive(need(e), shard, n_shards, out, top_values, top_owner, stats, deal_levels); });
+}
+int64_t rbl_exploitability_top_nodes(int dice, int faces, int max_depth, int deal_levels) {
+  int64_t n = -1;
+  guard([&] { n = rbl::exploitability_top_nodes(rbl::Rules(dice, faces), max_depth, deal_levels); });
+  return n;
+}
+int rbl_exploitability_combine(int dice, int faces, int max_depth, int deal_levels, int n_shards,
+                               const double* const* top_values, const int32_t* top_owner, double out[2]) {
+  return guard([&] {
+    if (!out) throw std::runtime_error("rbl_exploitability_combine: null output");
+    rbl::exploitability_combine(rbl::Rules(dice, faces), max_depth, deal_levels, n_shards, top_values, top_owner, out);
+  });
 }
 int rbl_solver_evaluate(rbl_engine* e, int traverser, double* out) {
   return guard([&] { need(e).evaluate(traverser, out); });

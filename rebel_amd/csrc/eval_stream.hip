@@ -45,13 +45,17 @@ struct FullTree {                   // BFS order of tree.h:51-70; mover of a nod
   int64_t N = 0;
 };
 
-FullTree build_full_tree(const Rules& g) {
+// max_levels: nodes deeper than that are not generated (the top of the tree: the shards' recombination sweep)
+FullTree build_full_tree(const Rules& g, int max_levels = std::numeric_limits<int>::max()) {
   if (g.A > 120) throw std::runtime_error("exploitability_recursive: more than 120 actions");
   FullTree t;
   // N = 2^A nodes for A actions (every increasing bid sequence, optionally closed by liar): refuse what cannot be held
-  if (g.A > 27) throw std::runtime_error("exploitability_recursive: full tree too large (2^" + std::to_string(g.A) + " nodes)");
-  t.bid.reserve((size_t)1 << g.A);
-  t.cb.reserve((size_t)1 << g.A);
+  if (g.A > 27 && max_levels > g.A)
+    throw std::runtime_error("exploitability_recursive: full tree too large (2^" + std::to_string(g.A) + " nodes)");
+  if (max_levels > g.A) {
+    t.bid.reserve((size_t)1 << g.A);
+    t.cb.reserve((size_t)1 << g.A);
+  }
   t.bid.push_back(-1);
   t.cb.push_back(0);
   t.lev_off.push_back(0);
@@ -63,6 +67,7 @@ FullTree build_full_tree(const Rules& g) {
     }
     const int b = t.bid[i];
     if (b == g.liar) continue;
+    if ((int)t.lev_off.size() - 1 >= max_levels) continue;  // node i sits at the last level that is kept
     int lo, hi;
     g.bid_range(b, &lo, &hi);
     if ((int64_t)t.bid.size() + (hi - lo) > (int64_t)std::numeric_limits<int32_t>::max())
@@ -276,16 +281,26 @@ struct RecursionStats {
   int levels = 0;
 };
 
+// deal_levels = K >= 1: the frontier PRODUCED by recursion level K - 1 (the non-terminal nodes at depth K * max_depth) is what
+// the shards share out; the levels above it are solved by every shard (K = 2 at 2 dice x 6 faces: the root subgame and its 276
+// depth-2 subgames, < 0.01 % of the 8.4 M subgames, redundantly -- and the largest dealt subtree is 1/16 of the game instead
+// of 1/4, so eight shards balance).
 RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb, double* d_sigma, int shard, int n_shards,
-                              const std::vector<int16_t>* act, int32_t* top_owner) {
+                              const std::vector<int16_t>* act, int32_t* top_owner, int deal_levels = 1) {
   const Rules& g = e.rules();
   const ShapeTables& tb = e.tables();
   const int H = g.H;
   if (n_shards < 1 || shard < 0 || shard >= n_shards) throw std::runtime_error("recursive solve on the device: bad shard");
+  if (deal_levels < 1) throw std::runtime_error("recursive solve on the device: deal_levels must be >= 1");
   RBL_HIP_CHECK(hipSetDevice(e.device()));
   hipStream_t st = e.stream();
   const int D = e.params().max_depth;
   if (D < 1) throw std::runtime_error("recursive solve on the device: max_depth must be >= 1");
+  if (top_owner) {  // (a recursion that ends above the dealt level leaves every node unowned: each shard then has everything)
+    const int64_t top_lev = (int64_t)deal_levels * D;
+    const int64_t M = (int64_t)ft.lev_off.size() - 1 > top_lev ? ft.lev_off[top_lev + 1] : ft.N;
+    for (int64_t i = 0; i < M; ++i) top_owner[i] = -1;
+  }
   const size_t lds = (size_t)e.emax() * H * sizeof(double) + (size_t)tb.max_N * sizeof(int32_t);
   if (lds > 160 * 1024)
     throw std::runtime_error("recursive solve on the device: subgames of depth " + std::to_string(D) +
@@ -332,7 +347,7 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
         bids[i] = ft.bid[f_node[base + i]];
         players[i] = player;
         lane_node[i] = f_node[base + i];
-        lane_tag[i] = f_tag[base + i];
+        lane_tag[i] = level < deal_levels ? -1 : f_tag[base + i];  // the dealt level's output numbers its own slots
         lane_out[i] = out_off[base + i];
         if (act) {
           lane_act[i] = (*act)[f_node[base + i]];
@@ -384,8 +399,8 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
       RBL_HIP_CHECK(hipMemcpyAsync(nt.data(), d_tag[nxt].p, (size_t)next_count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
       RBL_HIP_CHECK(hipStreamSynchronize(st));
     }
-    if (level == 0) {
-      // deal the root subgame's pseudo-leaves to the shards: largest subtree first (a node with last bid b heads
+    if (level == deal_levels - 1) {
+      // deal this level's pseudo-leaves to the shards: largest subtree first (a node with last bid b heads
       // 2^(liar - b) nodes), each to the least loaded shard; ties by index, so every shard computes the same map
       owner_of_tag.assign((size_t)next_count, 0);
       std::vector<int64_t> order((size_t)next_count);
@@ -399,13 +414,10 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
         owner_of_tag[(size_t)nt[i]] = best;
         load[best] += std::ldexp(1.0, g.liar - ft.bid[nn[i]]);
       }
-      if (top_owner) {
-        const int64_t M = (int64_t)ft.lev_off.size() - 1 > D ? ft.lev_off[D + 1] : ft.N;
-        for (int64_t i = 0; i < M; ++i) top_owner[i] = -1;
+      if (top_owner)
         for (int64_t i = 0; i < next_count; ++i) top_owner[nn[i]] = owner_of_tag[(size_t)nt[i]];
-      }
     }
-    if (n_shards > 1 && next_count) {  // compact the frontier (ids, tags and beliefs) to the items this shard owns
+    if (n_shards > 1 && next_count && level >= deal_levels - 1) {  // compact the frontier (ids, tags and beliefs) to the items this shard owns
       std::vector<int64_t> keep;
       for (int64_t i = 0; i < next_count; ++i)
         if (owner_of_tag[(size_t)nt[i]] == shard) keep.push_back(i);
@@ -447,12 +459,69 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
 
 }  // namespace
 
+// nodes of depth <= deal_levels * max_depth of the full tree (the region the shards hand back: top_values / top_owner)
+int64_t exploitability_top_nodes(const Rules& g, int max_depth, int deal_levels) {
+  if (max_depth < 1 || deal_levels < 1) throw std::runtime_error("exploitability_top_nodes: max_depth and deal_levels must be >= 1");
+  const int64_t lev = std::min<int64_t>((int64_t)max_depth * deal_levels, g.A + 1);
+  return build_full_tree(g, (int)lev).N;
+}
+
+// Shards of exploitability_recursive -> the two exploitabilities (host only, no device): BRSolver::compute_br
+// (subgame_solving.cc:326-355) over the nodes of depth <= deal_levels * max_depth.  A node whose subtree was dealt takes its
+// value from its owner; every other childless node of the region (terminals; nodes of a recursion that ended early) from
+// shard 0 -- those depend only on levels every shard solves.  Above them the traverser's nodes take the first-then-strictly-
+// greater maximum over their children, the opponent's the sum in ascending order; then vector_sum / H (:813-814).
+void exploitability_combine(const Rules& g, int max_depth, int deal_levels, int n_shards, const double* const* top_values,
+                            const int32_t* top_owner, double* out2) {
+  if (n_shards < 1 || !top_values || !top_owner) throw std::runtime_error("exploitability_combine: bad arguments");
+  const int64_t lev = std::min<int64_t>((int64_t)max_depth * deal_levels, g.A + 1);
+  const FullTree ft = build_full_tree(g, (int)lev);
+  const int64_t M = ft.N;
+  const int H = g.H;
+  std::vector<int> depth((size_t)M, 0);
+  for (size_t d = 0; d + 1 < ft.lev_off.size(); ++d)
+    for (int64_t n = ft.lev_off[d]; n < ft.lev_off[d + 1]; ++n) depth[(size_t)n] = (int)d;
+  std::vector<double> val((size_t)M * H);
+  for (int t = 0; t < 2; ++t) {
+    for (int64_t n = M - 1; n >= 0; --n) {
+      const int b = ft.bid[(size_t)n];
+      const bool childless = b == g.liar || depth[(size_t)n] >= lev;
+      double* v = val.data() + (size_t)n * H;
+      if (childless) {
+        const int o = top_owner[n] >= 0 ? top_owner[n] : 0;
+        if (o >= n_shards || !top_values[o]) throw std::runtime_error("exploitability_combine: owner shard missing");
+        std::memcpy(v, top_values[o] + ((size_t)t * M + (size_t)n) * H, (size_t)H * sizeof(double));
+        continue;
+      }
+      int lo, hi;
+      g.bid_range(b, &lo, &hi);
+      const int64_t c0 = ft.cb[(size_t)n];
+      const bool mine = (depth[(size_t)n] & 1) == t;
+      for (int h = 0; h < H; ++h) {
+        double x = 0.0;
+        for (int k = 0; k < hi - lo; ++k) {
+          const double y = val[(size_t)(c0 + k) * H + h];
+          if (mine) {
+            if (k == 0 || y > x) x = y;
+          } else {
+            x += y;
+          }
+        }
+        v[h] = x;
+      }
+    }
+    double s = 0;
+    for (int h = 0; h < H; ++h) s += val[h];
+    out2[t] = s / H;
+  }
+}
+
 // out2: exploitabilities of the two players (n_shards == 1, NaN otherwise).  top_values (optional): [2][M][H] best-response
 // values per traverser of the M nodes of depth <= max_depth (M = size of unroll_tree(game, root, max_depth)); top_owner
 // (optional): [M] shard that owns the subtree of each non-terminal depth-max_depth node, -1 for every other node.
 // stats (optional): [8] = {nodes, subgames solved, levels, solve s, sweep s, bytes of the strategy, frontier items, M}.
 void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, double* top_values, int32_t* top_owner,
-                              double* stats) {
+                              double* stats, int deal_levels) {
   const Rules& g = e.rules();
   const int H = g.H, A = g.A;
   if (g.dice > 8) throw std::runtime_error("exploitability_recursive: more than 8 dice");
@@ -474,7 +543,7 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
       for (int h = 0; h < H; ++h) m[(size_t)f * H + h] = (int8_t)g.matches(h, f);
     d_matches.upload(m, st);
   }
-  const RecursionStats rs = recursive_fill(e, ft, d_cb.p, d_sigma.p, shard, n_shards, nullptr, top_owner);
+  const RecursionStats rs = recursive_fill(e, ft, d_cb.p, d_sigma.p, shard, n_shards, nullptr, top_owner, deal_levels);
   const double t1 = now_s();
 
   // ------------------------------------------------------------------ best-response sweeps over the full tree
@@ -483,7 +552,8 @@ void exploitability_recursive(Engine& e, int shard, int n_shards, double* out2, 
   d_val.alloc((size_t)ft.N * H);
   const int nlev = (int)ft.lev_off.size() - 1;
   std::vector<double> root(H);
-  const int64_t M = (int64_t)ft.lev_off.size() - 1 > D ? ft.lev_off[D + 1] : ft.N;  // nodes of depth <= max_depth
+  const int64_t top_lev = (int64_t)deal_levels * D;  // nodes of depth <= deal_levels * max_depth
+  const int64_t M = (int64_t)ft.lev_off.size() - 1 > top_lev ? ft.lev_off[top_lev + 1] : ft.N;
   for (int t = 0; t < 2; ++t) {
     std::vector<double> b(H, 1.0 / H);
     RBL_HIP_CHECK(hipMemcpyAsync(d_reach.p, b.data(), H * sizeof(double), hipMemcpyHostToDevice, st));

@@ -1,0 +1,33 @@
+// rebel_amd/csrc/launch_timing.h -- gap-free kernel durations for the roofline figures.
+//
+// hipEventRecord before / after a launch brackets the kernel AND the dispatch gap in front of it (the start marker is
+// processed when the previous kernel retires; VERDICT r3 weak #7: the bench line's per-kernel event means summed to more than
+// the step they were taken in, and differed from rocprofv3's 301.9 / 53.4 us by 1-5 %).  hipExtLaunchKernelGGL binds a start
+// and a stop event to the dispatch packet itself: hipEventElapsedTime(start, stop) is then the kernel's own begin -> end
+// interval, the same two timestamps rocprofv3 --kernel-trace reports.  The engine arms this slot around a launch it wants
+// timed; a launcher that finds it armed launches through RBL_LAUNCH_TIMED and marks it used.
+#pragma once
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+namespace rbl {
+
+struct LaunchTimingSlot {
+  hipEvent_t start = nullptr, stop = nullptr;
+  int used = 0;  // launches that consumed the slot since it was armed (exactly 1 = a valid sample)
+};
+extern thread_local LaunchTimingSlot tl_launch_timing;
+
+}  // namespace rbl
+
+// launch `kernel`; when the calling thread armed the timing slot, bind its events to this dispatch
+#define RBL_LAUNCH_TIMED(kernel, grid, block, lds, stream, ...)                                                        \
+  do {                                                                                                                 \
+    ::rbl::LaunchTimingSlot& rbl_ts_ = ::rbl::tl_launch_timing;                                                        \
+    if (rbl_ts_.start) {                                                                                               \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, rbl_ts_.start, rbl_ts_.stop, 0, __VA_ARGS__);            \
+      ++rbl_ts_.used;                                                                                                  \
+    } else {                                                                                                           \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                               \
+    }                                                                                                                  \
+  } while (0)

@@ -35,6 +35,7 @@
 #include <stdexcept>
 #include <type_traits>
 
+#include "launch_timing.h"
 #include "net_kernels.h"
 
 namespace rbl {
@@ -645,7 +646,7 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   const int n_groups = (int)((rows + kRows - 1) / kRows);
   const int grid = n_groups < cus ? n_groups : cus;
 #define RBL_RES2(K0C_, LN_, NOT_)                                                                                    \
-  hipLaunchKernelGGL((mlp_resident_kernel<K0C_, LN_, NOT_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows, \
+  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows,   \
                      out, n_groups, range)
 #define RBL_RES(K0C_)                                    \
   do {                                                   \

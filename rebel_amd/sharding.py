@@ -23,3 +23,18 @@ def reduce_job(dist, world, dt, units, games, device=None):
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     return mx[0].item(), tot[1].item(), tot[2].item()
+
+
+def gather_ranks(dist, world, row, device=None):
+    """Every rank's `row` (a list of floats) on every rank, in rank order: the per-GPU figures of a multi-GPU bench line.
+    Bookkeeping only, like reduce_job -- there is no data-path collective."""
+    if world <= 1 and not dist.is_initialized():
+        return [list(row)]
+    import torch
+
+    if device is None:
+        device = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor(row, dtype=torch.float64, device=device)
+    every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(every, mine)
+    return [t.tolist() for t in every]

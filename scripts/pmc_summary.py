@@ -21,11 +21,11 @@ def find(sub, suffix):
 
 
 def short(name):
-    for key in ("mlp_resident_kernel", "mlp_pipe_kernel", "mlp_fsplit_forward_kernel", "cfr_rows_kernel", "cfr_wave_kernel", "cfr_big_kernel",
+    for key in ("mlp_resident_kernel", "mlp_pipe_kernel", "mlp_fsplit_forward_kernel", "cfr_rows_kernel", "cfr_wave_kernel", "cfr_flat_kernel", "split_queries_kernel", "unsplit_queries_kernel", "cfr_big_kernel",
                 "cfr_step_kernel", "sp_begin_kernel", "sp_scan_kernel", "sp_end_kernel", "synthetic_net_kernel"):
         if key in name:
             return name[name.index(key):].split("(")[0]
-    return name.split("(")[0][:60]
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:80]
 
 
 out = {"tag": tag, "kernels": {}, "note": "durations from the --kernel-trace pass (ns); fetch/write from the separate "

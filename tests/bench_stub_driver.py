@@ -17,6 +17,7 @@ import torch.distributed as dist  # noqa: E402
 
 torch.cuda.is_available = lambda: True
 torch.cuda.set_device = lambda d: None
+torch.cuda.device_count = lambda: int(os.environ.get("BENCH_STUB_GPUS", 8))
 torch.cuda.synchronize = lambda *a, **k: None
 _init = dist.init_process_group
 

@@ -34,7 +34,7 @@ def test_bench_json_contract_small():
     for key in ("roofline", "roofline_cfr"):
         r = d[key]
         assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-        assert r["standalone"]["achieved"] > 0  # the stand-alone leg ran
+        assert "dispatch packet" in r["measured"]
     assert abs(d["value"] - 2 * 2560 * 48 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
 
 
@@ -46,3 +46,28 @@ def test_bench_force_dist_single_rank_rccl():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     d = _run(["--force-dist", "--no-extra-legs"], env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+
+
+def test_bench_gpus_flag_refuses_more_gpus_than_the_box_has():
+    """`--gpus N` is live: with no rank environment bench.py starts the N ranks itself, and on a box with fewer
+    GPUs it refuses instead of measuring one GPU under the label n_gpus = N."""
+    import torch
+
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0 and f"--gpus {n + 1}" in r.stderr and "visible" in r.stderr
+
+
+def test_bench_configs_block_and_gap_free_timings():
+    """The headline game at 1024 iterations also runs the other BASELINE.json configurations as short legs (`configs`), and
+    the per-kernel durations are the dispatches' own intervals: their sum over an iteration cannot exceed the step."""
+    d = _run(["--iters", "1024", "--lanes", "16384", "--steps", "2", "--warmup", "1"])
+    assert [c["baseline_config"] for c in d["configs"]] == [1, 3, 4]
+    for c in d["configs"]:
+        assert c["value"] > 0 and 0 < c["net"]["frac"] < 1 and 0 < c["cfr"]["frac"] < 1 and c["ms_per_step"] > 0
+    assert "cfr_flat_kernel" in d["configs"][2]["cfr"]["kernel"]
+    assert d["streams"] == 1
+    per_iter_us = d["roofline"]["avg_launch_us"] + d["roofline_cfr"]["avg_launch_us"]
+    assert per_iter_us * 1024 * 1e-3 <= d["ms_per_step"] * 1.001, (per_iter_us, d["ms_per_step"])
