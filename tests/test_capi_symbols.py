@@ -77,3 +77,57 @@ def test_product_never_touches_the_oracle():
                 code = [l for l in lines if not l.strip().startswith(cmt)]
                 hits = [l for l in code if pat.search(l)]
                 assert not hits, (fn, hits[:3])
+
+
+def _combine_reference(dice, faces, levels, tops):
+    """The recombination sweep written out in numpy (the round-3 host implementation): BRSolver::compute_br,
+    subgame_solving.cc:326-355, over the top of the tree with every dealt node's value taken from its owner."""
+    from rebel_amd import capi
+
+    tree = capi.unroll_tree(dice, faces, -1, 0, levels)
+    owner = tops[0][1]
+    H = tops[0][0].shape[2]
+    out = np.zeros(2)
+    for t in range(2):
+        val = np.array(tops[0][0][t], dtype=np.float64, copy=True)
+        for n in range(len(tree) - 1, -1, -1):
+            last_bid, player, cb, ce = (int(x) for x in tree[n][:4])
+            if cb == ce:
+                if owner[n] >= 0:
+                    val[n] = tops[owner[n]][0][t][n]
+                continue
+            v = val[cb].copy()
+            for c in range(cb + 1, ce):
+                v = np.where(val[c] > v, val[c], v) if player == t else v + val[c]
+            val[n] = v
+        s = 0.0
+        for x in val[0]:
+            s += x
+        out[t] = s / H
+    return out
+
+
+@pytest.mark.parametrize("dice,faces,depth,deal", [(1, 4, 2, 1), (1, 4, 2, 2), (1, 6, 2, 2), (2, 3, 2, 2), (1, 4, 3, 1),
+                                                   (1, 4, 2, 8), (2, 6, 2, 2)])
+def test_exploitability_combine_is_host_code_of_the_c_abi(dice, faces, depth, deal):
+    """rbl_exploitability_combine / rbl_exploitability_top_nodes (the recombination of the shards existed
+    only in Python): host-only entry points, so they are exercised here without a GPU -- against the numpy sweep, on random
+    shard values and a random owner map."""
+    from rebel_amd import capi
+
+    L = capi.lib()
+    M = L.rbl_exploitability_top_nodes(dice, faces, depth, deal)
+    tree = capi.unroll_tree(dice, faces, -1, 0, depth * deal)
+    assert M == len(tree)
+    H = L.rbl_num_hands(dice, faces)
+    rng = np.random.default_rng(dice * 100 + faces * 10 + deal)
+    n_shards = 5
+    childless = np.array([int(r[2]) == int(r[3]) for r in tree])
+    liar = L.rbl_num_actions(dice, faces) - 1
+    dealt = childless & np.array([int(r[0]) != liar for r in tree])
+    owner = np.where(dealt, rng.integers(0, n_shards, M), -1).astype(np.int32)
+    tops = [(rng.normal(size=(2, M, H)), owner) for _ in range(n_shards)]
+    got = capi.combine_exploitability(dice, faces, depth, tops, deal_levels=deal)
+    assert np.array_equal(got, _combine_reference(dice, faces, depth * deal, tops))
+    with pytest.raises(Exception):
+        capi.combine_exploitability(dice, faces, depth, [(tops[0][0][:, :-1], owner[:-1])], deal_levels=deal)

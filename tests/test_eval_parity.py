@@ -73,7 +73,7 @@ def test_recursive_strategy_bit_exact(d, f, depth, iters, to_leaf, port):
 
 @pytest.mark.parametrize("d,f,depth,iters,use_cfr,lanes", [
     (1, 4, 2, 32, True, 64), (1, 4, 1, 10, True, 7), (1, 5, 2, 12, True, 48), (2, 2, 2, 20, True, 64), (1, 6, 2, 6, True, 512),
-    (1, 4, 2, 1, True, 64), (1, 4, 2, 16, False, 64), (1, 4, 3, 8, True, 32)])
+    (1, 4, 2, 1, True, 64), (1, 4, 2, 16, False, 64), (1, 4, 3, 8, True, 32), (2, 3, 2, 8, True, 512)])
 def test_streaming_exploitability_bit_exact(d, f, depth, iters, use_cfr, lanes, port):
     """rbl_exploitability_recursive (eval_stream.hip): the to-leaf recursion + compute_exploitability2 with
     the full-tree strategy device-resident and edge-indexed == the oracle's depth-first recursion + dense BR sweep, and ==
@@ -98,6 +98,20 @@ def test_streaming_exploitability_bit_exact(d, f, depth, iters, use_cfr, lanes, 
         assert all(np.array_equal(p[1][1], top[1] if n_shards == 1 else parts[0][1][1]) for p in parts)  # one owner map
         assert sum(p[2]["subgames"] for p in parts) == stats["subgames"] + (n_shards - 1)  # every shard solves the root
         assert np.array_equal(capi.combine_exploitability(d, f, depth, [p[1] for p in parts]), got)
+    # dealing the frontier of the SECOND recursion level: every shard redundantly solves the root subgame
+    # and its pseudo-leaves' subgames, the rest is shared out in pieces of at most 1/16 of the game; same number, bit for bit
+    one = e.exploitability_recursive(0, 1, deal_levels=2)
+    assert np.array_equal(one[0], got) and np.array_equal(capi.combine_exploitability(d, f, depth, [one[1]], deal_levels=2), got)
+    redundant = None
+    for n_shards in (2, 3, 8):
+        parts = [e.exploitability_recursive(s, n_shards, deal_levels=2) for s in range(n_shards)]
+        assert all(np.array_equal(p[1][1], parts[0][1][1]) for p in parts)
+        assert np.array_equal(capi.combine_exploitability(d, f, depth, [p[1] for p in parts], deal_levels=2), got), n_shards
+        # the levels above the dealt one are solved by every shard, everything below by exactly one
+        extra = sum(p[2]["subgames"] for p in parts) - stats["subgames"]
+        assert extra % (n_shards - 1) == 0
+        redundant = extra // (n_shards - 1) if redundant is None else redundant
+        assert extra // (n_shards - 1) == redundant and 1 <= redundant <= stats["subgames"]
 
 
 @pytest.mark.parametrize("d,f,depth,iters,seed,root_only,use_cfr", [
