@@ -109,7 +109,18 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Developer knock-outs for the ENERGY attribution of this kernel (scripts/power_attribution.sh; results are garbage, power and
+// time only): RBL_KO_MFMA drops the matrix instructions but keeps their operands alive (weight registers, B fragments from
+// LDS); RBL_KO_EPI drops LayerNorm scale / GELU / split (the activations are rounded to f16 and both halves carry the same).
+#ifdef RBL_KO_MFMA
+__device__ __forceinline__ f32x4 ko_mfma(f16x8 a, f16x8 b, f32x4 c) {
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+}
+#define RBL_MFMA(A_, B_, C_) ko_mfma((A_), (B_), (C_))
+#else
 #define RBL_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_16x16x32_f16((A_), (B_), (C_), 0, 0, 0)
+#endif
 
 // One dense layer for this wave's 2 x 4 output tiles with the weights already in registers.  A "step" is one (k-step,
 // row tile): two B fragments (hi, lo) from LDS feed 6 MFMAs (small products first, all into the same accumulator).
@@ -431,10 +442,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       for (int ot = 0; ot < kOTW; ++ot)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
+#ifdef RBL_KO_EPI
+          h[2 * ot + h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[ot][rt][2 * h2] * rs[rt], d[ot][rt][2 * h2 + 1]));
+          l[2 * ot + h2] = h[2 * ot + h2];
+#else
           const f32x2 a = f32x2{g4[ot][2 * h2], g4[ot][2 * h2 + 1]} * splat2(rs[rt]);
           const f32x2 y = gelu_z(fma2(f32x2{d[ot][rt][2 * h2], d[ot][rt][2 * h2 + 1]}, a,
                                       f32x2{o4[ot][2 * h2], o4[ot][2 * h2 + 1]}));
           split2(y[0], y[1], &h[2 * ot + h2], &l[2 * ot + h2]);
+#endif
         }
       Frag fh, fl;
       fh.h = f16x8{h[0][0], h[0][1], h[1][0], h[1][1], h[2][0], h[2][1], h[3][0], h[3][1]};

@@ -130,9 +130,12 @@ def main():
         os.environ["RBL_MLP_TILE"] = tile
         e.set_net_mlp(layers, ln, w_out, b_out)
         net_body()
-        phase(f"net forward, RBL_MLP_TILE={tile} ({ROWS} rows, canonical rows through the split kernel)", sampler, net_body, net_extra)
+        phase(f"net forward, RBL_MLP_TILE={tile} ({ROWS} rows, " + ("canonical rows" if os.environ.get("RBL_QSPLIT") == "0" else "canonical rows through the split kernel") + ")", sampler, net_body, net_extra)
     os.environ["RBL_MLP_TILE"] = "5"
     e.close()
+    if os.environ.get("POWER_TRACE_NET_ONLY"):
+        sampler.stop = True
+        return
 
     B = 16384
     ec = capi.Engine(1, 6, capi.make_params(num_iters=1024, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
