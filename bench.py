@@ -35,7 +35,6 @@ The JSON line also carries
                 generator-thread count in {16, 32, 60 (README), os.cpu_count()} -- a reported baseline, not a target.
 """
 import argparse
-import csv
 import glob
 import json
 import os
@@ -108,11 +107,13 @@ def rocprof_timed_epochs(kernel_key, steps_warmup):
             meta = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
             if meta.get("steps_warmup") != list(steps_warmup):
                 continue
-            for row in csv.DictReader(open(path)):
-                if any(k in row["kernel"] for k in kernel_key):
-                    return {"avg_launch_us": float(row["avg_ns_timed_epochs"]) / 1e3, "launches": int(row["launches_timed_epochs"]),
-                            "kernel": row["kernel"], "lanes_profiled": meta.get("lanes"),
-                            "source": os.path.relpath(path, ROOT)}
+            for line in open(path).read().splitlines()[1:]:
+                # kernel,launches_all,avg_ns_all,launches_timed_epochs,avg_ns_timed_epochs,bench_event_avg_ns -- the kernel
+                # name is a template instantiation with commas of its own (quoted from round 4 on)
+                name, _, _, n_timed, avg_timed, _ = line.rsplit(",", 5)
+                if any(k in name for k in kernel_key):
+                    return {"avg_launch_us": float(avg_timed) / 1e3, "launches": int(n_timed), "kernel": name.strip('"'),
+                            "lanes_profiled": meta.get("lanes"), "source": os.path.relpath(path, ROOT)}
         except Exception:
             continue
     return None
@@ -197,17 +198,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def make_net(dice, faces):
+    def make_net(dice, faces, half=False):
         torch.manual_seed(0)  # same random-init net on every rank (weights are read-only shared state)
         net = Net2(num_faces=faces, num_dice=dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
-        return mlp_weights_from_state_dict(net.state_dict())
+        if half:  # what the trainer's half_inference hands the generators: model.half() (cfvpy/selfplay.py:42-43)
+            net = net.half()
+        return mlp_weights_from_state_dict({k: v.float() for k, v in net.state_dict().items()})
 
-    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks):
+    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0):
         """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
         dice, faces, iters = game
         params = capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
         eng = capi.Engine(dice, faces, params, max_lanes=lanes, device=local_rank)
-        eng.set_net_mlp(*make_net(dice, faces))
+        eng.set_net_precision(precision)
+        eng.set_net_mlp(*make_net(dice, faces, half=precision != 0))
         sp = capi.SelfPlay(eng, lane_seeds(rank, lanes), random_action_prob=0.25, sample_leaf=True)
         for _ in range(warmup):
             sp.advance(collect=False)
@@ -265,13 +269,22 @@ def main():
         lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
                      "streams), same warm-up and timed epochs as the headline leg"}
 
+    half_leg = None
+    if world == 1 and not a.no_extra_legs:
+        # LABELLED EXTRA LEG, never the headline: the same workload with a half model (the trainer's `half_inference`) in the
+        # one-product arithmetic a half module selects (rbl_engine_set_net_precision 2: f16 activations x f16 weights, f32
+        # accumulation, f32 LayerNorm / GELU -- at least as accurate as the half torch module, tests/test_net_parity.py)
+        hdt, hunits, _, _, hst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False, precision=2)
+        half_leg = (hdt, hunits, hst)
+
     def roofline_blocks(game, st, streams_):
         """The `roofline` / `roofline_cfr` objects of one leg from its kernel stats."""
         dice, faces, _ = game
         n_t, c_t, n_tf, c_gb = kernel_figures(st)
         H_, A_ = faces ** dice, 2 * dice * faces + 1
         Q_ = 2 + A_ + 2 * H_
-        issued_ratio = 3.0 * (-(-Q_ // 32) * 32 * 256 + 256 * 256 + 256 * -(-H_ // 16) * 16) / (Q_ * 256 + 256 * 256 + 256 * H_)
+        prods = st.get("net_products", 3) or 3
+        issued_ratio = prods * (-(-Q_ // 32) * 32 * 256 + 256 * 256 + 256 * -(-H_ // 16) * 16) / (Q_ * 256 + 256 * 256 + 256 * H_)
         how = "HIP events bound to the dispatch packet (hipExtLaunchKernelGGL): the kernel's own begin -> end interval, as " \
               "rocprofv3 --kernel-trace reports it; "
         how += "one stream, net(all lanes) -> cfr(all lanes) per iteration: the kernel has the GPU to itself" if streams_ == 1 \
@@ -361,6 +374,16 @@ def main():
                               "ranks": [{"rank": int(r[0]), "gpu": int(r[1]), "value": r[2], "seconds": r[3], "net_frac_mfma": r[4],
                                          "cfr_frac_hbm": r[5], "cfr_gbps": r[6], "net_launch_us": r[7], "cfr_launch_us": r[8]}
                                         for r in per_rank]}
+        if half_leg:
+            hdt, hunits, hst = half_leg
+            hnet, hcfr = roofline_blocks(headline, hst, int(hst["n_streams"]))
+            out["half_inference"] = {
+                "label": "EXTRA LEG, not the headline: half model (cfvpy/selfplay.py half_inference), value-net GEMMs as ONE f16 "
+                         "MFMA product per multiply (f16 activations and weights, f32 accumulate, f32 LayerNorm/GELU)",
+                "value": hunits / hdt, "unit": "subgame-CFR-iterations/s", "ms_per_step": hdt / a.steps * 1e3,
+                "net": {k: hnet[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_us", "ns_per_row", "issued_mfma_tflops")},
+                "cfr": {k: hcfr[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_us")},
+                "net_products": hst.get("net_products")}
         if lanes4096:
             out["lanes_4096"] = lanes4096
         if two_streams:

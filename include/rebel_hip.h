@@ -80,6 +80,16 @@ void* rbl_engine_stream(rbl_engine* e); /* hipStream_t all engine work is enqueu
 int rbl_engine_set_net_zero(rbl_engine* e);
 int rbl_engine_set_net_synthetic(rbl_engine* e); /* test double, elementwise; same formula as oracle/orc_api.h */
 int rbl_engine_set_net_mlp(rbl_engine* e, const rbl_mlp_weights* w); /* ModelLocker ctor/updateModel, model_locker.h:56-79 */
+/* Arithmetic of the fused MLP forward, applied by the NEXT rbl_engine_set_net_mlp (cfvpy/selfplay.py:42-43, 211:
+ * `half_inference` turns the generating replicas into half modules):
+ *   0  f32 parity (default): activations and weights as f16 hi + lo pairs, three f16 MFMA products per multiply, f32
+ *      accumulation -- <= 1e-5 of the f32 module on O(1) outputs (4e-7 measured)
+ *   1  activations rounded to f16 once per layer (round to nearest), weights keep their hi + lo pair: two products
+ *   2  activations AND weights rounded to f16: one product -- the reference's half_inference semantics with f32
+ *      accumulation, f32 LayerNorm / GELU and one rounding per layer where a half torch module has three
+ * Modes 1 and 2 exist for Net2 with LayerNorm and one hidden layer of 256 (the register-resident kernel); anything else is
+ * refused by rbl_engine_set_net_mlp. */
+int rbl_engine_set_net_precision(rbl_engine* e, int mode);
 int rbl_engine_set_net_callback(rbl_engine* e, rbl_net_fn fn, void* user, int host_buffers);
 
 /* standalone batched forward of the current net (ModelLocker::forward, model_locker.h:85-95) */
@@ -233,9 +243,10 @@ typedef struct {
   /* what the engine actually launched last (reporting; not reset): CFR step kernel 0 generic (cfr_step_kernel), 1 one
    * thread per tree row (cfr_rows_kernel), 2 one wavefront per lane (cfr_wave_kernel), 3 rows kernel with global state
    * (2 dice x 6 faces, RBL_CFR_FLAT=0), 4 element-parallel kernel with sigma in LDS (cfr_flat_kernel, 2 dice x 6 faces);
-   * value-net kernel variant (MlpDev::tile: 6 pipelined, 5 register-resident, 3 feature split; 0 =
+   * value-net kernel variant (MlpDev::tile: 5 register-resident, 3 feature split; 0 =
    * no MLP net); number of lane parts = streams of the last batch */
-  int32_t cfr_kernel, net_kernel, n_streams, reserved;
+  int32_t cfr_kernel, net_kernel, n_streams;
+  int32_t net_products; /* f16 MFMA products per multiply of the MLP forward: 3, 2 or 1 (rbl_engine_set_net_precision); 0 = no MLP */
 } rbl_kernel_stats;
 /* stride = 0: off; n > 0: bracket the CFR and net launches of every n-th iteration with HIP events.  Use an ODD n: the
  * traverser of iteration i is i mod 2 and the two traversers' steps differ in cost (an even stride samples one of them only) */

@@ -24,7 +24,7 @@ EXAMPLE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.PO
 SYMBOLS = [
     "rbl_last_error", "rbl_device_count", "rbl_build_info", "rbl_num_actions", "rbl_num_hands", "rbl_query_size",
     "rbl_unroll_tree", "rbl_engine_create", "rbl_engine_destroy", "rbl_engine_stream", "rbl_engine_set_net_zero",
-    "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_callback", "rbl_net_forward",
+    "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_precision", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
     "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_exploitability_recursive_deal", "rbl_exploitability_top_nodes", "rbl_exploitability_combine", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
@@ -53,15 +53,14 @@ class KernelStats(C.Structure):
     _fields_ = [("cfr_ms", C.c_double), ("net_ms", C.c_double), ("cfr_launches", C.c_int64),
                 ("net_launches", C.c_int64), ("net_rows", C.c_int64), ("lane_steps", C.c_int64),
                 ("cfr_bytes", C.c_double), ("net_flops", C.c_double), ("cfr_kernel", C.c_int32), ("net_kernel", C.c_int32),
-                ("n_streams", C.c_int32), ("reserved", C.c_int32)]
+                ("n_streams", C.c_int32), ("net_products", C.c_int32)]
 
 
 CFR_KERNEL_NAMES = {0: "cfr_step_kernel (generic)", 1: "cfr_rows_kernel (one thread per tree row)",
                     2: "cfr_wave_kernel (one wavefront per lane)", 3: "cfr_rows_kernel<GS> (global state, 2dx6f)",
                     4: "cfr_flat_kernel (element-parallel, sigma in LDS, 2dx6f)"}
 NET_KERNEL_NAMES = {0: "none", 3: "mlp_fsplit_forward_kernel (feature split)",
-                    5: "mlp_resident_kernel (f16x2-split MFMA, register-resident weights)",
-                    6: "mlp_pipe_kernel (f16x2-split MFMA 32x32x16, software-pipelined)"}
+                    5: "mlp_resident_kernel (f16x2-split MFMA, register-resident weights)"}
 
 
 def make_params(num_iters=10, max_depth=2, linear_update=False, use_cfr=False, optimistic=False, dcfr=False,
@@ -107,6 +106,7 @@ def lib():
         "rbl_engine_set_net_synthetic": (C.c_int, [vp]),
         "rbl_engine_set_net_mlp": (C.c_int, [vp, C.POINTER(MlpWeights)]),
         "rbl_engine_set_net_callback": (C.c_int, [vp, NET_FN, vp, C.c_int]),
+        "rbl_engine_set_net_precision": (C.c_int, [vp, C.c_int]),
         "rbl_net_forward": (C.c_int, [vp, fp, C.c_int64, fp]),
         "rbl_net_forward_dev": (C.c_int, [vp, vp, C.c_int64, vp]),
         "rbl_solver_reset": (C.c_int, [vp, C.c_int, i32p, i32p, dp, i32p]),
@@ -283,6 +283,10 @@ class Engine:
         cb = NET_FN(_cb)
         self._keep.append(cb)
         _check(self.L.rbl_engine_set_net_callback(self.h, cb, None, 1))
+
+    def set_net_precision(self, mode):
+        """0 f32 parity (default), 1 half activations, 2 half activations and weights; applied by the next set_net_mlp."""
+        _check(self.L.rbl_engine_set_net_precision(self.h, int(mode)))
 
     def set_net_mlp(self, layers, ln, w_out, b_out, ln_eps=1e-5):
         """layers: [(W [hid,in], b [hid])...]; ln: [(g [hid], beta [hid])...] or None; torch Linear layout."""

@@ -66,6 +66,8 @@ class Engine {
   void set_net_zero();
   void set_net_synthetic();
   void set_net_mlp(const rbl_mlp_weights& w);
+  void set_net_precision(int mode);
+  int net_precision() const { return net_precision_; }
   void set_net_callback(rbl_net_fn fn, void* user, bool host_buffers);
   void net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, hipStream_t st = nullptr,
                        const long long* range = nullptr);  // async; `range`: see launch_mlp_forward
@@ -204,6 +206,7 @@ class Engine {
   // in use; the canonical [rows][Q] buffer is then current only after the init / query-only launches (get_queries rebuilds it)
   bool qsplit_ = false, q_canon_stale_ = false;
   int q_ds_ = 0, q_ss_ = 0, mlp_n_in_true_ = 0;
+  int net_precision_ = 0;  // rbl_engine_set_net_precision: applied by the next set_net_mlp
   DevBuf<float> d_qdyn_, d_qstat_, d_tmp_dyn_, d_tmp_stat_;
   void split_part_queries(int part, hipStream_t st);  // canonical rows of a lane part -> dyn / stat rows
   void leave_split_layout();  // net exchanged mid-solve: rebuild the canonical rows the next net reads (holds net_mutex_)

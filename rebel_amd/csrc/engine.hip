@@ -307,6 +307,12 @@ void Engine::set_net_callback(rbl_net_fn fn, void* user, bool host_buffers) {
   values_zeroed_ = false;
 }
 
+void Engine::set_net_precision(int mode) {
+  if (mode < 0 || mode > 2) throw std::runtime_error("set_net_precision: mode must be 0 (f32 parity), 1 or 2 (half_inference)");
+  std::lock_guard<std::mutex> net_lock(net_mutex_);
+  net_precision_ = mode;
+}
+
 void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   std::lock_guard<std::mutex> net_lock(net_mutex_);
   RBL_HIP_CHECK(hipSetDevice(device_));
@@ -365,6 +371,10 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   }
   mlp_.n_hidden = w.n_hidden;
   mlp_.n_out = w.n_out;
+  mlp_.products = 3 - net_precision_;
+  if (net_precision_ != 0 && (pk.tile != 5 || !w.use_layer_norm))
+    throw std::runtime_error("set_net_mlp: the half_inference modes need the register-resident kernel and a LayerNorm net "
+                             "(one hidden layer of 256; rbl_engine_set_net_precision(e, 0) for everything else)");
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
   mlp_.tile = pk.tile;
   if (env_int("RBL_NET_DBG", 0)) {
@@ -504,6 +514,7 @@ void Engine::stats(rbl_kernel_stats* out, bool reset) {
   stats_.cfr_kernel = last_cfr_kernel_;
   stats_.net_kernel = net_mode_ == NetMode::kMlp ? mlp_.tile : 0;
   stats_.n_streams = n_parts_;
+  stats_.net_products = net_mode_ == NetMode::kMlp ? mlp_.products : 0;
   if (out) *out = stats_;
   if (reset) stats_ = rbl_kernel_stats{};
 }
@@ -1801,6 +1812,9 @@ int rbl_engine_set_net_mlp(rbl_engine* e, const rbl_mlp_weights* w) {
     if (!w) throw std::runtime_error("rbl_engine_set_net_mlp: weights is null");
     need(e).set_net_mlp(*w);
   });
+}
+int rbl_engine_set_net_precision(rbl_engine* e, int mode) {
+  return guard([&] { need(e).set_net_precision(mode); });
 }
 int rbl_engine_set_net_callback(rbl_engine* e, rbl_net_fn fn, void* user, int host_buffers) {
   return guard([&] { need(e).set_net_callback(fn, user, host_buffers != 0); });

@@ -10,7 +10,7 @@ namespace rbl {
 // Device-resident, MFMA-ready copy of a Net2 (cfvpy/models.py:64-94).  Built by pack_mlp() from torch-layout weights.
 struct MlpDev {
   int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
-  int tile = 0;       // kernel variant: 6 = software-pipelined 32x32x16 (net_pipe_kernel.hip), 5 = register-resident, 3 = feature split
+  int tile = 0;       // kernel variant: 5 = register-resident, 3 = feature split
   const float* tape = nullptr;  // variant 0: the packed weights in consumption order, 32 KiB chunks
   int tape_chunks = 0, l0_chunks = 0;
   float inv_scale[8] = {1, 1, 1, 1, 1, 1, 1, 1};  // variant 2: 1 / (power-of-two weight scale) per layer (last = output)
@@ -30,6 +30,9 @@ struct MlpDev {
   // static rows [rows][q_stat_stride]; layer 0 is packed for the virtual input row (dyn row | stat row), n_in = the two strides
   const float* q_stat = nullptr;
   int q_dyn_stride = 0, q_stat_stride = 0;
+  // f16 products per multiply (tile 5): 3 = f16x2 split on both operands (f32 parity), 2 = activations rounded to f16,
+  // 1 = activations and weights rounded to f16 (half_inference); see net_resident_kernel.hip gemm_resident
+  int products = 3;
 };
 
 // Host-side packing: returns one float blob plus the offsets of the members above (in floats).
@@ -50,13 +53,6 @@ bool mlp_supported(int n_layers, int n_in, int n_hidden, int n_out);
 bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out);
 void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
                          const long long* range = nullptr);
-
-// net_pipe_kernel.hip (tile 6): 32x32x16 MFMA tiles, the epilogue of one 32-row tile software-pipelined into the MFMA
-// stream of its neighbours; one hidden layer of 256, n_in <= 47, n_out <= 32 (MlpDev::l0_chunks = 16-wide k-steps of
-// layer 0, MlpDev::out_tiles = groups of 8 outputs, MlpDev::stagger = feature tiles per wave, 1 or 2)
-bool mlp_pipe_supported(int n_layers, int n_in, int n_hidden, int n_out);
-void launch_mlp_pipe(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
-                     const long long* range = nullptr);
 
 // out[rows][n_out] = net(queries[rows][n_in]); f16x2-split MFMA (v_mfma_f32_16x16x32_f16), async on `stream`.
 // `range` (optional, device memory): the rows to process are [range[0], range[1]) of queries / out, known only on the

@@ -480,133 +480,14 @@ static MlpPacked pack_mlp_fsplit(int n_layers, int n_in, int n_hidden, int n_out
 }
 
 
-// Tile 6 (net_pipe_kernel.hip): v_mfma_f32_32x32x16_f16 fragments (lane = (m = lane % 32, h = lane / 32), 8 halves at
-// k = 16 ks + 8 h + p), 32-feature tiles.  Layer 0 in natural k order with its (centred) bias in the spare column
-// k = n_in; the hidden and the output layer with k permuted to the order in which the kernel's in-register epilogue
-// leaves the activations: (ks, h, p) <-> feature 16 ks + 8 (p / 4) + 4 h + p % 4.  Per-feature constants are stored in
-// the accumulator (D) layout [feature tile][h][i], feature = 32 ft + 8 (i / 4) + 4 h + i % 4.
-static MlpPacked pack_mlp_pipe(int n_in, int n_out, int use_ln, const float* const* w, const float* const* b,
-                               const float* const* ln_w, const float* const* ln_b, const float* w_out,
-                               const float* b_out) {
-  constexpr int NH = 256;
-  MlpPacked p;
-  p.tile = 6;
-  const int K0S = (n_in + 1 + 15) / 16, NO4 = (n_out + 7) / 8;
-  p.k0_steps = K0S;
-  p.l0_chunks = K0S;
-  p.out_tiles = NO4;
-  const size_t frag_f = 64 * 4;
-  p.off_w0 = 0;
-  p.off_wh = p.off_w0 + (size_t)8 * K0S * 2 * frag_f;
-  p.off_wo = p.off_wh + (size_t)8 * 16 * 2 * frag_f;
-  p.off_bias = p.off_wo + (size_t)16 * 2 * frag_f;
-  p.off_lnw = p.off_bias + NH;
-  p.off_lnb = p.off_lnw + 2 * NH;
-  p.off_bout = p.off_lnb + 2 * NH;
-  p.blob.assign(p.off_bout + 32, 0.f);
-  _Float16* tape = reinterpret_cast<_Float16*>(p.blob.data());
-  const double post = -1.41421356237309504880, pre = 0.70710678118654752440;
-  // centre each dense layer over its output features: the GEMM then produces y - mean(y) and only the variance is left
-  std::vector<double> wc0((size_t)NH * n_in), wc1((size_t)NH * NH), bc0(NH), bc1(NH);
-  for (int l = 0; l < 2; ++l) {
-    const int K = l == 0 ? n_in : NH;
-    std::vector<double>& wc = l == 0 ? wc0 : wc1;
-    std::vector<double>& bc = l == 0 ? bc0 : bc1;
-    for (int k = 0; k < K; ++k) {
-      double mu = 0;
-      for (int f = 0; f < NH; ++f) mu += w[l][(size_t)f * K + k];
-      mu = use_ln ? mu / NH : 0.0;
-      for (int f = 0; f < NH; ++f) wc[(size_t)f * K + k] = (double)w[l][(size_t)f * K + k] - mu;
-    }
-    double mb = 0;
-    for (int f = 0; f < NH; ++f) mb += b[l][f];
-    mb = use_ln ? mb / NH : 0.0;
-    for (int f = 0; f < NH; ++f) bc[f] = (double)b[l][f] - mb;
-  }
-  auto pow2_scale = [](double mx) {
-    if (!(mx > 0.0) || !std::isfinite(mx)) return 1.0;
-    return std::ldexp(1.0, (int)std::floor(std::log2(8192.0 / mx)));
-  };
-  auto put8 = [&](size_t frag, int lane, int e, double v, int part) {
-    const float vf = (float)v;
-    const _Float16 hi = (_Float16)vf;
-    const _Float16 lo = (_Float16)(vf - (float)hi);
-    tape[(frag * 64 + lane) * 8 + e] = part == 0 ? hi : lo;
-  };
-  p.inv_scale.assign(3, 1.f);
-  {  // layer 0
-    double mx = 0;
-    for (double v : wc0) mx = std::max(mx, std::fabs(v));
-    for (double v : bc0) mx = std::max(mx, std::fabs(v));
-    const double S = pow2_scale(mx);
-    p.inv_scale[0] = (float)(1.0 / S);
-    for (int ft = 0; ft < 8; ++ft)
-      for (int ks = 0; ks < K0S; ++ks)
-        for (int part = 0; part < 2; ++part)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-              const int f = 32 * ft + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + e;
-              const double v = k < n_in ? wc0[(size_t)f * n_in + k] * S : (k == n_in ? bc0[f] * S : 0.0);
-              put8(p.off_w0 / frag_f + ((size_t)(ft * K0S + ks) * 2 + part), lane, e, v, part);
-            }
-  }
-  auto perm_k = [](int ks, int h, int e) { return 16 * ks + 8 * (e >> 2) + 4 * h + (e & 3); };
-  {  // hidden layer
-    double mx = 0;
-    for (double v : wc1) mx = std::max(mx, std::fabs(v * post));
-    const double S = pow2_scale(mx);
-    p.inv_scale[1] = (float)(1.0 / S);
-    for (int ft = 0; ft < 8; ++ft)
-      for (int ks = 0; ks < 16; ++ks)
-        for (int part = 0; part < 2; ++part)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int e = 0; e < 8; ++e) {
-              const int f = 32 * ft + (lane & 31), k = perm_k(ks, lane >> 5, e);
-              put8(p.off_wh / frag_f + ((size_t)(ft * 16 + ks) * 2 + part), lane, e, wc1[(size_t)f * NH + k] * post * S, part);
-            }
-    for (int ft = 0; ft < 8; ++ft)
-      for (int h = 0; h < 2; ++h)
-        for (int i = 0; i < 16; ++i)
-          p.blob[p.off_bias + (ft * 2 + h) * 16 + i] = (float)(bc1[32 * ft + 8 * (i / 4) + 4 * h + i % 4] * S);
-  }
-  {  // output layer
-    double mx = 0;
-    for (size_t i = 0; i < (size_t)n_out * NH; ++i) mx = std::max(mx, std::fabs((double)w_out[i] * post));
-    const double S = pow2_scale(mx);
-    p.inv_scale[2] = (float)(1.0 / S);
-    for (int ks = 0; ks < 16; ++ks)
-      for (int part = 0; part < 2; ++part)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int e = 0; e < 8; ++e) {
-            const int o = lane & 31, k = perm_k(ks, lane >> 5, e);
-            put8(p.off_wo / frag_f + ((size_t)ks * 2 + part), lane, e, o < n_out ? (double)w_out[(size_t)o * NH + k] * post * S : 0.0,
-                 part);
-          }
-  }
-  for (int l = 0; l < 2; ++l)
-    for (int ft = 0; ft < 8; ++ft)
-      for (int h = 0; h < 2; ++h)
-        for (int i = 0; i < 16; ++i) {
-          const int f = 32 * ft + 8 * (i / 4) + 4 * h + i % 4;
-          p.blob[p.off_lnw + l * NH + (ft * 2 + h) * 16 + i] = (float)((use_ln ? (double)ln_w[l][f] : 1.0) * p.inv_scale[l] * pre);
-          p.blob[p.off_lnb + l * NH + (ft * 2 + h) * 16 + i] = use_ln ? (float)((double)ln_b[l][f] * pre) : 0.f;
-        }
-  for (int i = 0; i < n_out; ++i) p.blob[p.off_bout + i] = b_out[i];
-  return p;
-}
-
 MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, const float* const* w,
                    const float* const* b, const float* const* ln_w, const float* const* ln_b, const float* w_out,
                    const float* b_out, int tile) {
   if (!mlp_supported(n_layers, n_in, n_hidden, n_out))
     throw std::runtime_error(
         "value net shape not supported by the MFMA forward (n_hidden = 256, n_layers <= 7, n_in <= 128, n_out <= 64)");
-  if (tile != 3 && tile != 5 && tile != 6)
-    throw std::runtime_error("pack_mlp: kernel variant must be 6 (pipelined), 5 (resident) or 3 (feature split)");
-  // tile 6 takes the shapes it has instantiations for (K0S = 2, NO4 = 1: the 1-die games); others fall through to 5 / 3
-  if (tile == 6 && mlp_pipe_supported(n_layers, n_in, n_hidden, n_out) && (n_in + 1 + 15) / 16 == 2 && (n_out + 7) / 8 == 1)
-    return pack_mlp_pipe(n_in, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out);
-  if (tile == 6) tile = 5;
+  if (tile != 3 && tile != 5)
+    throw std::runtime_error("pack_mlp: kernel variant must be 5 (resident) or 3 (feature split)");
   if (tile == 5 && mlp_resident_supported(n_layers, n_in, n_hidden, n_out))
     return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, 8, true);
   return pack_mlp_fsplit(n_layers, n_in, n_hidden, n_out, use_ln, w, b, ln_w, ln_b, w_out, b_out, 8);
@@ -615,7 +496,6 @@ MlpPacked pack_mlp(int n_layers, int n_in, int n_hidden, int n_out, int use_ln, 
 void launch_mlp_forward(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
                         const long long* range) {
   if (rows <= 0) return;
-  if (m.tile == 6) return launch_mlp_pipe(m, queries, rows, out, stream, range);
   if (m.tile == 5) return launch_mlp_resident(m, queries, rows, out, stream, range);
   if (m.tile != 3) throw std::runtime_error("launch_mlp_forward: unknown kernel variant");
 #define RBL_FS(OT_) \

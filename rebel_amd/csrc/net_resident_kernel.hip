@@ -90,6 +90,10 @@ __device__ __forceinline__ void split2(float a, float b, f16x2* hi, f16x2* lo) {
   *lo = __builtin_bit_cast(f16x2, l);
 }
 
+// two f32 -> one f16 pair, round to nearest even (the half_inference modes keep no remainder, so the rounding is the error:
+// cvt_pkrtz's truncation would bias it and double its bound)
+__device__ __forceinline__ f16x2 pack_rne(float a, float b) { return __builtin_convertvector(f32x2{a, b}, f16x2); }
+
 // sum over the 8 lanes {l ^ 1, l ^ 16, l ^ 32} that share an image row, on the VALU (DPP + the gfx950 row / half swaps)
 // instead of three ds_bpermute round trips
 __device__ __forceinline__ float row_sum8(float s) {
@@ -129,7 +133,11 @@ __device__ __forceinline__ f32x4 ko_mfma(f16x8 a, f16x8 b, f32x4 c) {
 // has ~200 cycles of matrix work in front of it.
 // NRES k-steps with weights in wh / wl, then NTAIL more from th / tl (fragments requested from L2 just before the call:
 // they land while the resident k-steps are being multiplied); NT1 = max(NTAIL, 1) is only the array bound
-template <int NRES, int NTAIL, int NT1, int PF>
+// PROD: f16 products per multiply.  3 = x_h W_l + x_l W_h + x_h W_h (f32 parity, the default); 2 = x_h (W_l + W_h): the
+// activations are rounded to f16, the weights keep 22 bits; 1 = x_h W_h: activations and weights rounded to f16, f32
+// accumulation (the reference's half_inference, cfvpy/selfplay.py:42-43, with fewer roundings than a half torch module).
+// With PROD < 3 the lo fragments of the X image are neither written nor read.
+template <int NRES, int NTAIL, int NT1, int PF, int PROD>
 __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW],
                                               const Frag (&th)[NT1][kOTW], const Frag (&tl)[NT1][kOTW],
                                               const f32x4* __restrict__ X, int lane, f32x4 (&acc)[kOTW][kRT]) {
@@ -139,7 +147,7 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
 #pragma unroll
   for (int s = 0; s < PF && s < NS; ++s) {
     xb[s][0].v = X[(((s / kRT) * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
-    xb[s][1].v = X[(((s / kRT) * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
+    if (PROD == 3) xb[s][1].v = X[(((s / kRT) * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -147,7 +155,7 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
     if (s + PF < NS) {
       const int n = s + PF, nslot = n % (PF + 1);
       xb[nslot][0].v = X[(((n / kRT) * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
-      xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
+      if (PROD == 3) xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
 #ifdef RBL_SPLIT_KS
@@ -159,12 +167,16 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
 #endif
     const bool tail = ks >= NRES;
     const int kr = tail ? 0 : ks, kt = tail ? ks - NRES : 0;
+    if (PROD >= 2) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot)
-      acc[ot][rt] = RBL_MFMA(tail ? tl[kt][ot].h : wl[kr][ot].h, xb[slot][0].h, acc[ot][rt]);
+      for (int ot = 0; ot < kOTW; ++ot)
+        acc[ot][rt] = RBL_MFMA(tail ? tl[kt][ot].h : wl[kr][ot].h, xb[slot][0].h, acc[ot][rt]);
+    }
+    if (PROD == 3) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot)
-      acc[ot][rt] = RBL_MFMA(tail ? th[kt][ot].h : wh[kr][ot].h, xb[slot][1].h, acc[ot][rt]);
+      for (int ot = 0; ot < kOTW; ++ot)
+        acc[ot][rt] = RBL_MFMA(tail ? th[kt][ot].h : wh[kr][ot].h, xb[slot][1].h, acc[ot][rt]);
+    }
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot)
       acc[ot][rt] = RBL_MFMA(tail ? th[kt][ot].h : wh[kr][ot].h, xb[slot][0].h, acc[ot][rt]);
@@ -177,7 +189,7 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
 // and are there; once they have been used, `fetch_late` requests the remaining ones INTO THE SAME REGISTERS, and the resident
 // k-steps (>= 16 steps of matrix work per wave) cover that round trip.  Streamed weights so never hold more than NEARLY k-steps
 // of registers (2 x 16 VGPRs instead of up to 64: what hipcc could not fit and spilled from the resident set).
-template <int NRES, int NTAIL, int NEARLY, int NE1, int PF, class FetchLate>
+template <int NRES, int NTAIL, int NEARLY, int NE1, int PF, int PROD, class FetchLate>
 __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW], Frag (&th)[NE1][kOTW],
                                             Frag (&tl)[NE1][kOTW], const f32x4* __restrict__ X, int lane,
                                             f32x4 (&acc)[kOTW][kRT], FetchLate&& fetch_late) {
@@ -190,7 +202,7 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
   for (int s = 0; s < PF && s < NS; ++s) {
     const int k = ks_of(s / kRT);
     xb[s][0].v = X[((k * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
-    xb[s][1].v = X[((k * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
+    if (PROD == 3) xb[s][1].v = X[((k * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -198,18 +210,22 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
     if (s + PF < NS) {
       const int n = s + PF, nslot = n % (PF + 1), k = ks_of(n / kRT);
       xb[nslot][0].v = X[((k * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
-      xb[nslot][1].v = X[((k * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
+      if (PROD == 3) xb[nslot][1].v = X[((k * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool res = p >= NEARLY && p < NEARLY + NRES;
     const int kr = res ? p - NEARLY : 0;
     const int kt = res ? 0 : (p < NEARLY ? p : p - NRES - NEARLY);  // register slot of a streamed k-step
+    if (PROD >= 2) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot)
-      acc[ot][rt] = RBL_MFMA(res ? wl[kr][ot].h : tl[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
+      for (int ot = 0; ot < kOTW; ++ot)
+        acc[ot][rt] = RBL_MFMA(res ? wl[kr][ot].h : tl[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
+    }
+    if (PROD == 3) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot)
-      acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][1].h, acc[ot][rt]);
+      for (int ot = 0; ot < kOTW; ++ot)
+        acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][1].h, acc[ot][rt]);
+    }
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot)
       acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
@@ -227,7 +243,7 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
 // through the X image.  (The X-image loop is compiled into variant 4 only: next to the prefetched layer-0 weights of the next
 // group its fragments pushed the K0C = 4 kernel 40 VGPRs over budget, and hipcc spilled RESIDENT hidden weights for it --
 // reloaded from scratch, with a full vmcnt wait, inside the hidden GEMM of every group.)
-template <int K0C, bool LN, int NOTV>
+template <int K0C, bool LN, int NOTV, int PROD>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups,
                                                                     const long long* __restrict__ range) {
@@ -299,7 +315,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #pragma unroll
       for (int ot = 0; ot < kOTW; ++ot) {
         w1h[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-        w1l[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        if (PROD >= 2) w1l[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
       }
   }
   // per-feature parameters and the first output tile's weights: LDS copies (read every group, by every thread)
@@ -379,7 +395,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       for (int t = 0; t < NOT; ++t) {
         const int tt = t < m.out_tiles ? t : 0;
         woh[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 0) * 64 + lane];
-        wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
+        if (PROD >= 2) wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
       }
     }
     f32x4 d[kOTW][kRT];
@@ -449,7 +465,12 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
           const f32x2 a = f32x2{g4[ot][2 * h2], g4[ot][2 * h2 + 1]} * splat2(rs[rt]);
           const f32x2 y = gelu_z(fma2(f32x2{d[ot][rt][2 * h2], d[ot][rt][2 * h2 + 1]}, a,
                                       f32x2{o4[ot][2 * h2], o4[ot][2 * h2 + 1]}));
-          split2(y[0], y[1], &h[2 * ot + h2], &l[2 * ot + h2]);
+          if (PROD == 3) {
+            split2(y[0], y[1], &h[2 * ot + h2], &l[2 * ot + h2]);
+          } else {
+            h[2 * ot + h2] = pack_rne(y[0], y[1]);
+            l[2 * ot + h2] = f16x2{(_Float16)0.f, (_Float16)0.f};
+          }
 #endif
         }
       Frag fh, fl;
@@ -457,14 +478,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       fl.h = f16x8{l[0][0], l[0][1], l[1][0], l[1][1], l[2][0], l[2][1], l[3][0], l[3][1]};
       if (!kLast || NOTV == 4) {
         X[((wave * 2 + 0) * kRT + rt) * 64 + lane] = fh.v;
-        X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
+        if (PROD == 3) X[((wave * 2 + 1) * kRT + rt) * 64 + lane] = fl.v;
       }
       if constexpr (kLast) {  // this wave's 32-wide k slice of the output layer, summed over the waves below
 #pragma unroll
         for (int t = 0; t < NOT; ++t) {
           if (t > 0 && t >= m.out_tiles) break;
-          f32x4 o = RBL_MFMA(wol[t].h, fh.h, (f32x4{0.f, 0.f, 0.f, 0.f}));
-          o = RBL_MFMA(woh[t].h, fl.h, o);
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (PROD >= 2) o = RBL_MFMA(wol[t].h, fh.h, o);
+          if (PROD == 3) o = RBL_MFMA(woh[t].h, fl.h, o);
           o = RBL_MFMA(woh[t].h, fh.h, o);
           // partials of tile 0 have their own buffer; those of tiles 1, 2 take over the X image, which nobody reads between
           // the first barrier of this epilogue (every wave is past the hidden GEMM) and the next group's staging
@@ -488,7 +510,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #pragma unroll
       for (int ot = 0; ot < kOTW; ++ot) {
         th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-        tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        if (PROD >= 2) tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
       }
   };
   fetch_w0();
@@ -510,11 +532,17 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #pragma unroll
       for (int ks = 0; ks < K0C; ++ks) {
         f16x2 h0, l0, h1, l1;
-        split2(qn[ks][0], qn[ks][1], &h0, &l0);
-        split2(qn[ks][2], qn[ks][3], &h1, &l1);
+        if (PROD == 3) {
+          split2(qn[ks][0], qn[ks][1], &h0, &l0);
+          split2(qn[ks][2], qn[ks][3], &h1, &l1);
+        } else {  // the query, too, is rounded to f16 (the half module's first op: query.half())
+          h0 = pack_rne(qn[ks][0], qn[ks][1]);
+          h1 = pack_rne(qn[ks][2], qn[ks][3]);
+          l0 = l1 = f16x2{(_Float16)0.f, (_Float16)0.f};
+        }
         const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
         X8[(((ks * 2 + 0) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, hh);
-        X8[(((ks * 2 + 1) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, ll);
+        if (PROD == 3) X8[(((ks * 2 + 1) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, ll);
       }
     }
     lds_barrier();
@@ -523,7 +551,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
     // -------------------------------------------------------------- layer 0
     zero_acc();
-    gemm_resident<K0C, 0, K0C, kPF>(th, tl, th, tl, X, lane, acc);
+    gemm_resident<K0C, 0, K0C, kPF, PROD>(th, tl, th, tl, X, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     // The streamed k-steps of the hidden layer take over registers of the layer-0 weights (dead from here on): the first kEarly
     // of them are requested BEFORE the layer-0 epilogue, whose ~6 k cycles cover the L2 round trips; the rest is requested
@@ -539,7 +567,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         for (int ot = 0; ot < kOTW; ++ot) {
           const int sl = ks - decltype(lo_tag)::value + decltype(slot0_tag)::value;
           t7h[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-          t7l[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+          if (PROD >= 2) t7l[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
         }
     };
     using I0 = std::integral_constant<int, 0>;
@@ -553,9 +581,9 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     // -------------------------------------------------------------- hidden layer, weights from registers
     zero_acc();
     if constexpr (kTail == 0)
-      gemm_resident<kRes, 0, 1, kPF>(w1h, w1l, t7h, t7l, X, lane, acc);
+      gemm_resident<kRes, 0, 1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc);
     else
-      gemm_hidden<kRes, kTail, kEarly, kE1, kPF>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(IE{}, IT{}, I0{}); });
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(IE{}, IT{}, I0{}); });
     RBL_NSTAMP();  // 5: hidden gemm
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
@@ -605,11 +633,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         const int ks = kh * 4 + s4;
         Frag wh, wl, xh, xl;
         wh.v = wo[(ks * 2 + 0) * 64 + lane];
-        wl.v = wo[(ks * 2 + 1) * 64 + lane];
         xh.v = X[((ks * 2 + 0) * kRT + rt) * 64 + lane];
-        xl.v = X[((ks * 2 + 1) * kRT + rt) * 64 + lane];
-        a2 = RBL_MFMA(wl.h, xh.h, a2);
-        a3 = RBL_MFMA(wh.h, xl.h, a3);
+        if (PROD >= 2) {
+          wl.v = wo[(ks * 2 + 1) * 64 + lane];
+          a2 = RBL_MFMA(wl.h, xh.h, a2);
+        }
+        if (PROD == 3) {
+          xl.v = X[((ks * 2 + 1) * kRT + rt) * 64 + lane];
+          a3 = RBL_MFMA(wh.h, xl.h, a3);
+        }
         a1 = RBL_MFMA(wh.h, xh.h, a1);
       }
       const f32x4 o = a1 + (a2 + a3);
@@ -661,9 +693,17 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   const int cus = dev < 64 ? n_cu[dev] : 256;
   const int n_groups = (int)((rows + kRows - 1) / kRows);
   const int grid = n_groups < cus ? n_groups : cus;
-#define RBL_RES2(K0C_, LN_, NOT_)                                                                                    \
-  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows,   \
-                     out, n_groups, range)
+#define RBL_RES3(K0C_, LN_, NOT_, PROD_)                                                                                  \
+  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows, \
+                   out, n_groups, range)
+  // the half_inference modes (MlpDev::products 2 / 1) are built for LayerNorm nets only (the reference's configuration)
+#define RBL_RES2(K0C_, LN_, NOT_)                                             \
+  do {                                                                        \
+    if (m.products == 3) RBL_RES3(K0C_, LN_, NOT_, 3);                        \
+    else if (LN_ && m.products == 2) RBL_RES3(K0C_, true, NOT_, 2);           \
+    else if (LN_ && m.products == 1) RBL_RES3(K0C_, true, NOT_, 1);           \
+    else throw std::runtime_error("launch_mlp_resident: unsupported products / LayerNorm combination"); \
+  } while (0)
 #define RBL_RES(K0C_)                                    \
   do {                                                   \
     if (m.use_ln) {                                      \
@@ -686,6 +726,7 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   }
 #undef RBL_RES
 #undef RBL_RES2
+#undef RBL_RES3
 }
 
 }  // namespace rbl

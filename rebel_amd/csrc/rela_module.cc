@@ -530,6 +530,7 @@ struct MlpHost {  // weights in torch.nn.Linear layout, owned
   int n_layers = 0, n_in = 0, n_hidden = 0, n_out = 0, use_ln = 0;
   std::vector<std::vector<float>> w, b, ln_w, ln_b;
   std::vector<float> w_out, b_out;
+  bool half = false;  // the module's parameters are torch.float16 (selfplay.py:42-43, 211: half_inference)
 };
 
 std::vector<float> to_floats(const py::handle& t) {
@@ -608,6 +609,8 @@ bool parse_net2_map(const std::map<std::string, torch::Tensor>& sd, MlpHost* out
   m.n_out = (int)so[0];
   m.w_out = to_floats(sd.at("output.weight"));
   m.b_out = to_floats(sd.at("output.bias"));
+  m.half = true;
+  for (const auto& kv : sd) m.half = m.half && kv.second.scalar_type() == torch::kHalf;
   *out = std::move(m);
   return true;
 }
@@ -643,6 +646,18 @@ int apply_mlp(rbl_engine* e, const MlpHost& mlp) {
   c.w_out = mlp.w_out.data();
   c.b_out = mlp.b_out.data();
   c.ln_eps = 1e-5f;
+  // A half module (the trainer's `half_inference`): its own arithmetic is f16 activations x f16 weights.  Mode 2 of the fused
+  // forward computes that with f32 accumulation and f32 LayerNorm / GELU (fewer roundings than the module itself);
+  // REBEL_AMD_HALF_INFERENCE=1 keeps the packed weights' low halves (two products), =0 computes a half module in full f32
+  // parity arithmetic (three products, rounds 1-3 behaviour).  f32 modules always run mode 0.
+  int mode = 0;
+  if (mlp.half) {
+    const char* env = std::getenv("REBEL_AMD_HALF_INFERENCE");
+    mode = env ? std::atoi(env) : 2;
+    if (mode < 0 || mode > 2) mode = 2;
+    if (!mlp.use_ln || mlp.n_layers != 2 || mlp.n_hidden != 256) mode = 0;
+  }
+  if (int st = rbl_engine_set_net_precision(e, mode)) return st;
   return rbl_engine_set_net_mlp(e, &c);
 }
 

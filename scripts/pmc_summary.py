@@ -64,7 +64,7 @@ try:
             if key in n and len(v) % (wu + st) == 0 and len(v) >= 64:
                 v.sort()
                 timed = [x[1] for x in v[len(v) * wu // (wu + st):]]
-                lines.append(f"{n},{len(v)},{sum(x[1] for x in v) / len(v):.1f},{len(timed)},{sum(timed) / len(timed):.1f},"
+                lines.append(f"\"{n}\",{len(v)},{sum(x[1] for x in v) / len(v):.1f},{len(timed)},{sum(timed) / len(timed):.1f},"
                              f"{bj[field]['avg_launch_us'] * 1000:.1f}")
     open(os.path.join(base, f"{tag}_kernel_stats_timed_epochs.csv"), "w").write("\n".join(lines) + "\n")
 except Exception as ex:  # summary only

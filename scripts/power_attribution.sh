@@ -13,7 +13,7 @@ for v in ko_mfma ko_epi "ko_mfma ko_epi"; do
   n=$(echo $v | tr ' ' '_'); flags=""
   for f in $v; do flags="$flags -DRBL_$(echo $f | tr a-z A-Z)"; done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result $flags -c net_resident_kernel.hip -o $S/nrk_$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $S/librebel_hip_$n.so $(ls _build/*.o | grep -v net_resident_kernel.o) $S/nrk_$n.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $S/librebel_hip_$n.so $(ls _build/*.o | grep -v -e net_resident_kernel.o -e rela_module.o) $S/nrk_$n.o
 done
 cd $R
 export RBL_QSPLIT=0 POWER_TRACE_TILES="5" POWER_TRACE_NET_ONLY=1

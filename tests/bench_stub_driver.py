@@ -43,6 +43,9 @@ class Engine:
     def set_net_mlp(self, *a):
         pass
 
+    def set_net_precision(self, mode):
+        pass
+
     def sync(self):
         pass
 
@@ -51,7 +54,7 @@ class Engine:
 
     def stats(self, reset=False):
         return dict(cfr_ms=1.0, net_ms=1.0, cfr_launches=1, net_launches=1, net_rows=64, lane_steps=0, cfr_bytes=1e6,
-                    net_flops=1e9, cfr_kernel=2, net_kernel=5, n_streams=1)
+                    net_flops=1e9, cfr_kernel=2, net_kernel=5, n_streams=1, net_products=3)
 
     def close(self):
         pass

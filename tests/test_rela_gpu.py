@@ -173,19 +173,32 @@ def test_half_precision_model_through_model_locker():
     assert np.abs(y - want16).max() <= 2e-2 * max(1.0, np.abs(want32).max())
 
 
-def test_rela_lane_matches_capi_lane():
-    """The examples a rela lane pushes are exactly those of the C-ABI self-play lane with the same seed."""
+@pytest.mark.parametrize("half_model,env_mode", [(False, None), (True, None), (True, "1"), (True, "0")])
+def test_rela_lane_matches_capi_lane(half_model, env_mode, monkeypatch):
+    """The examples a rela lane pushes are exactly those of the C-ABI self-play lane with the same seed.  A half module
+    (the trainer's half_inference, cfvpy/selfplay.py:42-43, 211) selects the one-product arithmetic of
+    rbl_engine_set_net_precision(e, 2); REBEL_AMD_HALF_INFERENCE=1 / 0 select modes 1 / 0 for it."""
     import torch
 
     import rebel_amd.rela as rela
     from rebel_amd import capi
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
 
+    if env_mode is not None:
+        monkeypatch.setenv("REBEL_AMD_HALF_INFERENCE", env_mode)
     d, f, iters = 1, 4, 32
     torch.manual_seed(3)
     net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+    if half_model:
+        with torch.no_grad():
+            net.output.weight *= 30
+            net.output.bias *= 30
+        net = net.half()
     e = capi.Engine(d, f, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), max_lanes=1)
-    e.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
+    mode = 0 if not half_model else (2 if env_mode is None else int(env_mode))
+    e.set_net_precision(mode)
+    e.set_net_mlp(*mlp_weights_from_state_dict({k: v.float() for k, v in net.state_dict().items()}))
+    assert e.stats()["net_products"] == 3 - mode
     sp = capi.SelfPlay(e, [42])
     want_q, want_v = [], []
     for _ in range(6):
