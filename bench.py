@@ -80,6 +80,55 @@ def cpu_baseline(dice, faces, iters, seconds, threads=0):
                           f"synthetic net instead of Net2 (so this OVERSTATES the CPU path)"}
 
 
+class PowerSampler:
+    """Socket power and gfx clock of GPU `index` during a timed region (amdsmi gpu_metrics, ~10 ms): the value-net forward runs
+    AT the socket's power cap (profiles/r04_net_energy_attribution.txt), so the line carries the power it was measured at."""
+
+    def __init__(self, index):
+        import threading
+
+        self.samples, self.stop, self.smi = [], False, None
+        try:
+            import amdsmi
+
+            amdsmi.amdsmi_init()
+            self.h = amdsmi.amdsmi_get_processor_handles()[index]
+            self.smi = amdsmi
+            self.cap_w = float(amdsmi.amdsmi_get_power_cap_info(self.h)["power_cap"]) / 1e6
+            self._read()
+        except Exception:  # no SMI access on this box: the block is simply absent
+            self.smi = None
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        m = self.smi.amdsmi_get_gpu_metrics_info(self.h)
+        clks = [c for c in (m.get("current_gfxclks") or []) if isinstance(c, (int, float)) and 0 < c < 10000]
+        pw = m.get("current_socket_power")
+        if not isinstance(pw, (int, float)) or not 0 < pw < 5000:
+            pw = m.get("average_socket_power")
+        return time.perf_counter(), float(pw or 0), (sum(clks) / len(clks)) if clks else float(m.get("current_gfxclk") or 0)
+
+    def _run(self):
+        while not self.stop and self.smi:
+            try:
+                self.samples.append(self._read())
+            except Exception:
+                return
+            time.sleep(0.01)
+
+    def start(self):
+        if self.smi:
+            self.t.start()
+
+    def summary(self, t0, t1):
+        self.stop = True
+        s = [x for x in self.samples if t0 <= x[0] <= t1]
+        if not s:
+            return None
+        return {"mean_socket_power_w": sum(x[1] for x in s) / len(s), "mean_gfxclk_mhz": sum(x[2] for x in s) / len(s),
+                "power_cap_w": self.cap_w, "samples": len(s), "source": "amdsmi gpu_metrics at ~10 ms over the timed region"}
+
+
 def spawn_ranks(n_gpus):
     """`--gpus N` without a rank environment: start the N ranks ourselves, one process per GPU (torch.distributed.run)."""
     import torch
@@ -205,7 +254,9 @@ def main():
             net = net.half()
         return mlp_weights_from_state_dict({k: v.float() for k, v in net.state_dict().items()})
 
-    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0):
+    power = {}
+
+    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0, sample_power=False):
         """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
         dice, faces, iters = game
         params = capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
@@ -219,6 +270,9 @@ def main():
         eng.stats(reset=True)
         eng.timing(timing_stride)
         n_ex, games0, units = 0, sp.games_finished(), 0
+        sampler = PowerSampler(local_rank) if sample_power else None
+        if sampler:
+            sampler.start()
         if sync_ranks:
             barrier()
         t0 = time.perf_counter()
@@ -230,6 +284,8 @@ def main():
         if sync_ranks:
             barrier()
         dt = time.perf_counter() - t0
+        if sampler:
+            power["headline"] = sampler.summary(t0, t0 + dt)
         st = eng.stats(reset=True)
         eng.timing(0)
         games = sp.games_finished() - games0
@@ -246,7 +302,7 @@ def main():
         return net_t, cfr_t, net_tf, cfr_gb
 
     headline = (a.dice, a.faces, a.iters)
-    dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True)
+    dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True, sample_power=rank == 0)
     net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
 
     dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
@@ -369,6 +425,9 @@ def main():
                 rp["achieved"] = work / (rp["avg_launch_us"] * 1e-6)
                 rp["frac"] = rp["achieved"] / out[key]["peak"]
                 out[key]["rocprof"] = rp
+        if power.get("headline"):
+            # the dominant kernel is socket-power-bound (84 % of the step at ~1.39 kW of a 1.4 kW cap): see DESIGN.md 3.2d
+            out["power"] = power["headline"]
         if per_rank:
             out["per_gpu"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
                               "ranks": [{"rank": int(r[0]), "gpu": int(r[1]), "value": r[2], "seconds": r[3], "net_frac_mfma": r[4],

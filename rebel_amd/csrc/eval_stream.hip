@@ -267,6 +267,15 @@ __global__ void br_value_kernel(const SweepArgs a) {
   a.val[n * H + h] = x;
 }
 
+// beliefs of a batch's lanes gathered from the frontier's slots (lanes sorted by stop iteration sit in other slots than their
+// frontier order): dst[i][2][H] = src[slot[i]][2][H]
+__global__ void gather_beliefs_kernel(const double* __restrict__ src, const int64_t* __restrict__ slot, double* __restrict__ dst,
+                                      int n, int row) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * row) return;
+  dst[i] = src[slot[i / row] * row + i % row];
+}
+
 double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -307,8 +316,8 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
                              " do not fit the scatter kernel's LDS image (" + std::to_string(lds) + " bytes)");
   RBL_HIP_CHECK(hipFuncSetAttribute((const void*)scatter_strategy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DevBuf<int32_t> d_node[2], d_lane_node, d_tag[2], d_lane_tag;
-  DevBuf<int64_t> d_lane_out;
-  DevBuf<double> d_bel[2];
+  DevBuf<int64_t> d_lane_out, d_slot;
+  DevBuf<double> d_bel[2], d_gather;
 
   // ------------------------------------------------------------------ recursion, level by level
   std::vector<int32_t> f_node{0};
@@ -329,6 +338,24 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
   while (!f_node.empty()) {
     const size_t count = f_node.size();
     const int player = (int)(((int64_t)level * D) & 1);
+    // Sampled strategies: a lane stops at its own act_iteration and a batch runs to its LARGEST one.  In frontier order every
+    // batch of a wide level contains a lane near num_iters; sorted by stop iteration (descending, stable) the batches run
+    // num_iters, ..., 0 steps: about half the work at the wide levels.  Subgames of a level are independent and every output is
+    // keyed by node id, so the order of the lanes changes no result; only the beliefs must be fetched from the lanes' slots.
+    std::vector<int64_t> slot_of;  // frontier slot (= position of the beliefs in d_bel[cur]) of the i-th lane in solve order
+    if (act && count > (size_t)e.max_lanes()) {
+      slot_of.resize(count);
+      for (size_t i = 0; i < count; ++i) slot_of[i] = (int64_t)i;
+      std::stable_sort(slot_of.begin(), slot_of.end(),
+                       [&](int64_t x, int64_t y) { return (*act)[f_node[(size_t)x]] > (*act)[f_node[(size_t)y]]; });
+      std::vector<int32_t> sn(count), stg(count);
+      for (size_t i = 0; i < count; ++i) {
+        sn[i] = f_node[(size_t)slot_of[i]];
+        stg[i] = f_tag[(size_t)slot_of[i]];
+      }
+      f_node.swap(sn);
+      f_tag.swap(stg);
+    }
     // the frontier of the next level: every pseudo-leaf of every subgame of this level (a non-terminal node always has children)
     std::vector<int64_t> out_off(count + 1, 0);
     for (size_t i = 0; i < count; ++i) out_off[i + 1] = out_off[i] + tb.shapes[ft.bid[f_node[i]] + 1].L;
@@ -339,8 +366,18 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
     d_bel[nxt].alloc((size_t)std::max<int64_t>(1, next_count) * 2 * H);
     for (size_t base = 0; base < count; base += maxB) {
       const int B = (int)std::min<size_t>(maxB, count - base);
-      RBL_HIP_CHECK(hipMemcpyAsync(bel_host.data(), d_bel[cur].p + base * 2 * H, (size_t)B * 2 * H * sizeof(double),
-                                   hipMemcpyDeviceToHost, st));
+      if (slot_of.empty()) {
+        RBL_HIP_CHECK(hipMemcpyAsync(bel_host.data(), d_bel[cur].p + base * 2 * H, (size_t)B * 2 * H * sizeof(double),
+                                     hipMemcpyDeviceToHost, st));
+      } else {
+        d_slot.upload(std::vector<int64_t>(slot_of.begin() + base, slot_of.begin() + base + B), st);
+        if (d_gather.n < (size_t)B * 2 * H) d_gather.alloc((size_t)maxB * 2 * H);
+        const int64_t work = (int64_t)B * 2 * H;
+        hipLaunchKernelGGL(gather_beliefs_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, d_bel[cur].p, d_slot.p,
+                           d_gather.p, B, 2 * H);
+        RBL_HIP_CHECK(hipGetLastError());
+        RBL_HIP_CHECK(hipMemcpyAsync(bel_host.data(), d_gather.p, (size_t)B * 2 * H * sizeof(double), hipMemcpyDeviceToHost, st));
+      }
       RBL_HIP_CHECK(hipStreamSynchronize(st));
       int steps = act ? 0 : -1;
       for (int i = 0; i < B; ++i) {
