@@ -204,6 +204,21 @@ const char* rbl_stream_last_error(void);
  * rbl_stream_sampled_reset: forget the repeats. */
 int rbl_stream_sampled_reset(rbl_stream* s);
 int rbl_stream_sampled_add(rbl_stream* s, rbl_engine* e, int seed);
+/* The same repeat with root_only = true (recursive_solving.cc:318-320, recursive_eval --root_only): the root subgame on a lane
+ * of `e`, then every subgame below it solved to the END OF THE GAME (max_depth = 100000, no value net), each stopped at its own
+ * act_iteration.  Those subgames (276 trees of up to 4 M nodes at 2 dice x 6 faces) are solved together as a forest on the
+ * full tree's edge-indexed arrays: level-synchronous CFR sweeps over the nodes below depth max_depth, every node gated by the
+ * stop iteration of its subtree.  Bit-identical to rbl_strategy_recursive_sampled(e, seed, 1) where that fits. */
+int rbl_stream_sampled_add_root_only(rbl_stream* s, rbl_engine* e, int seed);
+/* report_regrets of the same tool (recursive_eval.cc:28-53 -> compute_immediate_regrets, subgame_solving.cc:984-1050) without
+ * the list of dense strategies: regrets accumulate on the device, strategy by strategy.  regrets_add(which): RBL_GET_LAST = the
+ * full-tree solver's current sampling strategy (the tool lists it after every even iteration, :285-287); RBL_GET_SAMPLED = the
+ * last sampled repeat, rounded to float as the tool's tensor round trip does (:357-358).  regrets_report: first[n_first][H] =
+ * immediate regrets of the first nodes (the tool prints 20), sums = {vector_sum over the nodes of depth < `depth`, over the
+ * rest}.  Bit-identical to rbl_immediate_regrets on the same strategies. */
+int rbl_stream_regrets_reset(rbl_stream* s);
+int rbl_stream_regrets_add(rbl_stream* s, int which);
+int rbl_stream_regrets_report(rbl_stream* s, int depth, int n_first, double* first, double sums[2]);
 int rbl_stream_sampled_eval(rbl_stream* s, double exploitability[2], double ev_of_full[2]);
 
 /* ---- self-play lanes: RlRunner (recursive_solving.h:40-86), one per seed (create_cfr_thread, pybind.cc:36-43) ---- */

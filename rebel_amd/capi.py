@@ -27,7 +27,7 @@ SYMBOLS = [
     "rbl_engine_set_net_synthetic", "rbl_engine_set_net_mlp", "rbl_engine_set_net_precision", "rbl_engine_set_net_callback", "rbl_net_forward",
     "rbl_net_forward_dev", "rbl_solver_reset", "rbl_solver_step", "rbl_solver_multistep", "rbl_solver_sync",
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
-    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_exploitability_recursive_deal", "rbl_exploitability_top_nodes", "rbl_exploitability_combine", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
+    "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_exploitability_recursive_deal", "rbl_exploitability_top_nodes", "rbl_exploitability_combine", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_add_root_only", "rbl_stream_regrets_reset", "rbl_stream_regrets_add", "rbl_stream_regrets_report", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
@@ -144,6 +144,10 @@ def lib():
         "rbl_stream_last_error": (C.c_char_p, []),
         "rbl_stream_sampled_reset": (C.c_int, [vp]),
         "rbl_stream_sampled_add": (C.c_int, [vp, vp, C.c_int]),
+        "rbl_stream_sampled_add_root_only": (C.c_int, [vp, vp, C.c_int]),
+        "rbl_stream_regrets_reset": (C.c_int, [vp]),
+        "rbl_stream_regrets_add": (C.c_int, [vp, C.c_int]),
+        "rbl_stream_regrets_report": (C.c_int, [vp, C.c_int, C.c_int, dp, dp]),
         "rbl_stream_sampled_eval": (C.c_int, [vp, dp, dp]),
         "rbl_selfplay_create": (vp, [vp, C.c_int, i32p, C.c_double, C.c_int]),
         "rbl_selfplay_destroy": (None, [vp]),
@@ -471,9 +475,25 @@ class StreamSolver:
     def sampled_reset(self):
         self._ck(self.L.rbl_stream_sampled_reset(self.h))
 
-    def sampled_add(self, engine, seed):
-        """One repeat of the tool's "Recursive solving" on the lanes of `engine` (max_depth = mdp_depth, its net)."""
-        self._ck(self.L.rbl_stream_sampled_add(self.h, engine.h, int(seed)))
+    def regrets_reset(self):
+        self._ck(self.L.rbl_stream_regrets_reset(self.h))
+
+    def regrets_add(self, which):
+        """One more strategy of report_regrets' list: GET_LAST (the full-tree solver's sampling strategy) or GET_SAMPLED."""
+        self._ck(self.L.rbl_stream_regrets_add(self.h, int(which)))
+
+    def regrets_report(self, depth, n_first=20):
+        """-> (immediate regrets [min(n_first, N)][H], (sum over depth < `depth`, sum over the rest))."""
+        nf = int(min(n_first, self.nodes))
+        first, sums = np.zeros((nf, self.H)), np.zeros(2)
+        self._ck(self.L.rbl_stream_regrets_report(self.h, int(depth), nf, _p(first, C.c_double), _p(sums, C.c_double)))
+        return first, (float(sums[0]), float(sums[1]))
+
+    def sampled_add(self, engine, seed, root_only=False):
+        """One repeat of compute_sampled_strategy_recursive_to_leaf(seed, root_only) on `engine`'s lanes (root_only: the subgames
+        below the root subgame solved to the end of the game, as a forest on this solver's arrays)."""
+        fn = self.L.rbl_stream_sampled_add_root_only if root_only else self.L.rbl_stream_sampled_add
+        self._ck(fn(self.h, engine.h, int(seed)))
 
     def sampled_eval(self):
         """(exploitability2 of the mean of the repeats, compute_ev2(full-tree average, mean of the repeats))."""

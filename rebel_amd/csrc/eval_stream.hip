@@ -189,6 +189,13 @@ struct SweepArgs {
   int64_t n0, n1;            // node range of the level being processed
   int H, A, faces, dice, liar;
   int trav, level;           // traverser; depth of the nodes n0..n1
+  // forest solve (sampled_add with root_only): sub[n] = which dealt subtree node n belongs to, act_sub[s] = the iteration at
+  // which subtree s stops; a node whose subtree has stopped is skipped by every pass (its sigma is that subgame's sampling
+  // strategy from then on).  nullptr: no gating
+  const int32_t* sub = nullptr;
+  const int32_t* act_sub = nullptr;
+  int iter = 0;
+  int round32 = 0;  // regret reports: the strategy went through a float tensor (recursive_eval.cc:357-358): round on read
 };
 
 // opponent reach of the children of level `level` (precompute_reaches, subgame_solving.cc:54-78): thread per (node, hand)
@@ -200,12 +207,16 @@ __global__ void br_reach_kernel(const SweepArgs a) {
   const int h = (int)(i % H);
   const int b = a.f_bid[n];
   if (b == a.liar) return;
+  if (a.sub && a.iter >= a.act_sub[a.sub[n]]) return;
   const int cnt = b < 0 ? a.A - 1 : a.A - 1 - b;  // bid_range: bids b + 1 .. A - 2, plus liar unless at the root
   const int64_t c0 = a.f_cb[n];
   const double up = a.reach[n * H + h];
   const bool opp_moves = (a.level & 1) != a.trav;
-  for (int k = 0; k < cnt; ++k)
-    a.reach[(c0 + k) * H + h] = opp_moves ? up * a.sigma_full[(c0 + k - 1) * H + h] : up;
+  for (int k = 0; k < cnt; ++k) {
+    double sg = opp_moves ? a.sigma_full[(c0 + k - 1) * H + h] : 1.0;
+    if (a.round32) sg = (double)(float)sg;
+    a.reach[(c0 + k) * H + h] = opp_moves ? up * sg : up;
+  }
 }
 
 // Terminal payoffs (compute_expected_terminal_values :80-98, compute_win_probability :765-789) of the liar children of the
@@ -217,6 +228,7 @@ __global__ void terminal_value_kernel(const SweepArgs a) {
   if (n >= a.n1) return;
   const int b = a.f_bid[n];
   if (b == a.liar || b < 0) return;  // terminals have no children; the root's children are all bids
+  if (a.sub && a.iter >= a.act_sub[a.sub[n]]) return;
   const int H = a.H, cnt = a.A - 1 - b;
   const int64_t z = (int64_t)a.f_cb[n] + cnt - 1;  // the liar child is the last one
   const int qty = 1 + b / a.faces, face = b % a.faces;
@@ -295,7 +307,11 @@ struct RecursionStats {
 // depth-2 subgames, < 0.01 % of the 8.4 M subgames, redundantly -- and the largest dealt subtree is 1/16 of the game instead
 // of 1/4, so eight shards balance).
 RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb, double* d_sigma, int shard, int n_shards,
-                              const std::vector<int16_t>* act, int32_t* top_owner, int deal_levels = 1) {
+                              const std::vector<int16_t>* act, int32_t* top_owner, int deal_levels = 1,
+                              int max_levels = std::numeric_limits<int>::max(), std::vector<int32_t>* last_nodes = nullptr,
+                              DevBuf<double>* last_beliefs = nullptr) {
+  // max_levels: stop after that many recursion levels and hand the frontier they produced (node ids, and the beliefs
+  // [count][2][H] on the device) to the caller instead of following it (root_only repeats: the forest solve takes over)
   const Rules& g = e.rules();
   const ShapeTables& tb = e.tables();
   const int H = g.H;
@@ -486,6 +502,14 @@ RecursionStats recursive_fill(Engine& e, const FullTree& ft, const int32_t* d_cb
     f_tag.swap(nt);
     cur = nxt;
     ++level;
+    if (level >= max_levels) {
+      if (last_nodes) *last_nodes = f_node;
+      if (last_beliefs) {
+        std::swap(last_beliefs->p, d_bel[cur].p);
+        std::swap(last_beliefs->n, d_bel[cur].n);
+      }
+      break;
+    }
   }
   RecursionStats rs;
   rs.n_subgames = n_subgames;
@@ -667,6 +691,9 @@ struct StepArgs {
   int H, A, faces, dice, liar, trav, level;
   double pos, neg, strat;
   int steps0, steps1;
+  const int32_t* sub = nullptr;  // forest solve: see SweepArgs
+  const int32_t* act_sub = nullptr;
+  int iter = 0;
 };
 
 __device__ __forceinline__ int child_count(int b, int A) { return b < 0 ? A - 1 : A - 1 - b; }
@@ -705,6 +732,7 @@ __global__ void st_value_kernel(const StepArgs a) {
   const int h = (int)(i % H);
   const int b = a.f_bid[n];
   if (b == a.liar) return;
+  if (a.sub && a.iter >= a.act_sub[a.sub[n]]) return;
   const int cnt = child_count(b, a.A);
   const int64_t c0 = a.f_cb[n];
   const bool mine = (a.level & 1) == a.trav;
@@ -780,6 +808,46 @@ __global__ void st_average_kernel(const StepArgs a) {
     const int64_t e = (c0 + k - 1) * H + h;
     a.avg[e] = untouched ? 1. / cnt : a.sums[e] / s;
   }
+}
+
+// ---- forest solve: every non-terminal node of one level is the root of an independent full-depth subgame (root_only repeats)
+// CFR ctor on the nodes of a level (:509-534 without sum_strategies, which the sampling strategy does not read)
+__global__ void forest_init_kernel(const StepArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const double u = 1. / cnt;
+  for (int k = 0; k < cnt; ++k) {
+    a.sigma[(c0 + k - 1) * H + h] = u;
+    a.regrets[(c0 + k - 1) * H + h] = 0.0;
+  }
+}
+// which subtree a node belongs to: roots number themselves, everybody below inherits (thread per parent)
+__global__ void forest_sub_kernel(const int8_t* f_bid, const int32_t* f_cb, int32_t* sub, int64_t n0, int64_t n1, int A, int liar,
+                                  int is_root_level) {
+  const int64_t n = n0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n1) return;
+  if (is_root_level) sub[n] = (int32_t)(n - n0);
+  const int b = f_bid[n];
+  if (b == liar) return;
+  const int me = is_root_level ? (int32_t)(n - n0) : sub[n];
+  const int cnt = child_count(b, A);
+  const int64_t c0 = f_cb[n];
+  for (int k = 0; k < cnt; ++k) sub[c0 + k] = me;
+}
+// reach of player `pl` at the subgame roots = their beliefs: reach[node[i]][h] = bel[i][pl][h]
+__global__ void forest_root_reach_kernel(const int32_t* node, const double* bel, double* reach, int64_t count, int H, int pl) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * H) return;
+  const int64_t k = i / H;
+  const int h = (int)(i % H);
+  reach[(int64_t)node[k] * H + h] = bel[(k * 2 + pl) * H + h];
 }
 
 // ---- sampled repeats (recursive_eval.cc:136-160, 336-363).  The reference keeps float32 tensors summed_strategy
@@ -861,6 +929,67 @@ __global__ void ev_value_kernel(const SweepArgs a, const double* sigma_own) {
   a.val[n * H + h] = x;
 }
 
+// compute_immediate_regrets (subgame_solving.cc:984-1050), one (strategy, traverser) sweep: values bottom-up under the strategy,
+// regrets[node][hand][action] += value(child), then -= value(node) at the traverser's nodes -- accumulated over strategies
+__global__ void ir_value_kernel(const SweepArgs a, double* regrets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int H = a.H;
+  const int64_t n = a.n0 + i / H;
+  if (n >= a.n1) return;
+  const int h = (int)(i % H);
+  const int b = a.f_bid[n];
+  if (b == a.liar) return;
+  const int cnt = child_count(b, a.A);
+  const int64_t c0 = a.f_cb[n];
+  const bool mine = (a.level & 1) == a.trav;
+  double x = 0.0;
+  if (mine) {
+    for (int k = 0; k < cnt; ++k) {
+      double sg = a.sigma_full[(c0 + k - 1) * H + h];
+      if (a.round32) sg = (double)(float)sg;
+      x += a.val[(c0 + k) * H + h] * sg;
+    }
+    for (int k = 0; k < cnt; ++k) {
+      const int64_t e = (c0 + k - 1) * H + h;
+      double r = regrets[e];
+      r += a.val[(c0 + k) * H + h];
+      r -= x;
+      regrets[e] = r;
+    }
+  } else {
+    for (int k = 0; k < cnt; ++k) x += a.val[(c0 + k) * H + h];
+  }
+  a.val[n * H + h] = x;
+}
+// immediate_regrets[node][hand] = max over the DENSE action row / n_strategies (:1041-1046): every node has at least one
+// illegal action, whose regret stays 0, so the maximum is never negative; 0 on nodes without children
+__global__ void ir_max_kernel(const int8_t* f_bid, const int32_t* f_cb, const double* regrets, double* out, int64_t N, int H, int A,
+                              int liar, double n_strategies) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * H) return;
+  const int64_t n = i / H;
+  const int h = (int)(i % H);
+  const int b = f_bid[n];
+  double best = 0.0;
+  if (b != liar) {
+    const int cnt = child_count(b, A);
+    const int64_t c0 = f_cb[n];
+    for (int k = 0; k < cnt; ++k) {
+      const double r = regrets[(c0 + k - 1) * H + h];
+      best = r > best ? r : best;
+    }
+    best = best / n_strategies;
+  }
+  out[i] = best;
+}
+__global__ void ir_node_sum_kernel(const double* v, double* out, int64_t N, int H) {  // vector_sum per node (util.h:87-90)
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double sum = 0.0;
+  for (int h = 0; h < H; ++h) sum += v[n * H + h];
+  out[n] = sum;
+}
+
 // act_iteration of every subgame of the recursion, drawn in the order the reference constructs its solvers
 // (recursive_solving.cc:301-327 + :96-131: a subgame, then depth-first each of its pseudo-leaves in the partial tree's
 // BFS order = ascending full-tree id).  The weights emulate linear averaging: even iterations only, weight i / 2 + 1.
@@ -898,6 +1027,22 @@ std::vector<int16_t> draw_act_iterations(const FullTree& ft, const Rules& g, int
   return act;
 }
 
+// The same with root_only (:318-320): the subgames below the root subgame run to the end of the game, so the recursion is two
+// levels deep -- the root's draw, then one draw per pseudo-leaf of the root subgame in ascending full-tree id.  Returns the root's
+// act_iteration; `leaf_act[i]` belongs to the i-th non-terminal node of depth D.
+int draw_act_iterations_root_only(const FullTree& ft, const Rules& g, int D, int num_iters, int seed, std::vector<int32_t>* leaf_act) {
+  std::mt19937 gen(seed);
+  std::vector<double> w;
+  for (int i = 0; i < num_iters; ++i) w.push_back(i % 2 ? 0.0 : (i / 2. + 1));
+  std::discrete_distribution<int> dist(w.begin(), w.end());
+  const int root = dist(gen);
+  leaf_act->clear();
+  if ((int)ft.lev_off.size() - 1 > D)
+    for (int64_t n = ft.lev_off[D]; n < ft.lev_off[D + 1]; ++n)
+      if (ft.bid[n] != g.liar) leaf_act->push_back(dist(gen));
+  return root;
+}
+
 }  // namespace
 
 struct StreamSolver {
@@ -911,6 +1056,10 @@ struct StreamSolver {
   DevBuf<double> d_sigma, d_regrets, d_sums, d_avg, d_reach, d_val;
   DevBuf<double> d_samp, d_final;  // sampled repeats: the current repeat's strategy, the reach-weighted mean of all
   DevBuf<float> d_sstrat, d_sreach;
+  DevBuf<double> d_ir;  // regret reports: regrets accumulated over a list of strategies (compute_immediate_regrets)
+  int n_ir = 0;
+  DevBuf<double> f_sigma, f_regrets;  // forest solve (root_only repeats): sigma and regrets of the subgames below the root's
+  DevBuf<int32_t> f_sub, f_act, f_nodes;
   int n_samples = 0;
   double sample_seconds = 0;
   int iter = 0, num_steps[2] = {0, 0};
@@ -1123,6 +1272,121 @@ struct StreamSolver {
     const std::vector<int16_t> act = draw_act_iterations(ft, g, e.params().max_depth, e.params().num_iters, seed);
     recursive_fill(e, ft, d_cb.p, d_samp.p, 0, 1, &act, nullptr);
     RBL_HIP_CHECK(hipSetDevice(device));
+    accumulate_sample();
+    ++n_samples;
+    sample_seconds += now_s() - t0;
+  }
+  // one repeat with root_only (recursive_solving.cc:318-320; recursive_eval --root_only): the root subgame on a lane of `e`
+  // (depth max_depth, value net, stopped at its act_iteration), then EVERY subgame below it solved to the end of the game --
+  // at 2 dice x 6 faces those are 276 trees of up to 4 M nodes, far beyond a lane: they are solved together as a FOREST on the
+  // full tree's edge-indexed arrays, level-synchronously like the full-tree solver above, every node gated by the stop
+  // iteration of the subtree it belongs to.  The subgames are independent, start together (so the traverser of iteration i
+  // is i mod 2 for all, :666-670) and a stopped subtree's sigma IS its sampling strategy (get_sampling_strategy, :682-688).
+  void sampled_add_root_only(Engine& e, int seed) {
+    if (e.device() != device || e.rules().dice != g.dice || e.rules().faces != g.faces)
+      throw std::runtime_error("sampled_add: the engine is for another device or game");
+    if (!d_samp.p) sampled_reset();
+    const double t0 = now_s();
+    const int H = g.H, D = e.params().max_depth;
+    std::vector<int32_t> leaf_act;
+    const int root_act = draw_act_iterations_root_only(ft, g, D, e.params().num_iters, seed, &leaf_act);
+    // the root subgame: recursive_fill's first level with the root's own stop iteration; it scatters the sampling strategy
+    // to the edges above depth D and leaves the frontier (nodes in ascending id, normalised beliefs) on the device
+    std::vector<int16_t> act((size_t)ft.N, (int16_t)-1);
+    act[0] = (int16_t)root_act;
+    std::vector<int32_t> nodes;
+    DevBuf<double> bel;
+    recursive_fill(e, ft, d_cb.p, d_samp.p, 0, 1, &act, nullptr, 1, 1, &nodes, &bel);
+    RBL_HIP_CHECK(hipSetDevice(device));
+    const int64_t count = (int64_t)nodes.size();
+    if (count != (int64_t)leaf_act.size()) throw std::runtime_error("sampled_add(root_only): frontier / draw count mismatch");
+    if (count > 0) {
+      const int nl = nlev();
+      const size_t eh = (size_t)std::max<int64_t>(1, ft.N - 1) * H;
+      if (!f_sigma.p) {
+        f_sigma.alloc(eh);
+        f_regrets.alloc(eh);
+        f_sub.alloc((size_t)ft.N);
+        // subtree ids: the nodes of depth D number themselves (terminals included: they have no descendants), top-down
+        for (int lev = D; lev + 1 <= nl; ++lev) {
+          const int64_t n0 = ft.lev_off[lev], n1 = ft.lev_off[lev + 1];
+          hipLaunchKernelGGL(forest_sub_kernel, dim3((unsigned)((n1 - n0 + 255) / 256)), dim3(256), 0, st, d_bid.p, d_cb.p, f_sub.p,
+                             n0, n1, g.A, g.liar, lev == D ? 1 : 0);
+        }
+        RBL_HIP_CHECK(hipGetLastError());
+      }
+      // stop iteration per subtree id (= position in level D); terminals of that level never take part
+      std::vector<int32_t> act_sub((size_t)(ft.lev_off[D + 1] - ft.lev_off[D]), 0);
+      int max_act = 0;
+      for (int64_t i = 0; i < count; ++i) {
+        act_sub[(size_t)(nodes[(size_t)i] - ft.lev_off[D])] = leaf_act[(size_t)i];
+        max_act = std::max(max_act, leaf_act[(size_t)i]);
+      }
+      f_act.upload(act_sub, st);
+      f_nodes.upload(nodes, st);
+      StepArgs a = args(0);
+      a.sigma = f_sigma.p;
+      a.regrets = f_regrets.p;
+      for (int lev = D; lev + 1 < nl; ++lev) {
+        level(a, lev);
+        hipLaunchKernelGGL(forest_init_kernel, grid(a), dim3(256), 0, st, a);
+      }
+      RBL_HIP_CHECK(hipGetLastError());
+      int steps[2] = {0, 0};
+      for (int it = 0; it < max_act; ++it) {
+        const int t = it % 2;
+        const double sdisc = steps[t] + 1;
+        double pos = 1, neg = 1;
+        if (p.linear_update) {
+          pos = neg = sdisc / (sdisc + 1);
+        } else if (p.dcfr) {
+          pos = p.dcfr_alpha >= 5 ? 1 : std::pow(sdisc, p.dcfr_alpha) / (std::pow(sdisc, p.dcfr_alpha) + 1.);
+          neg = p.dcfr_beta <= -5 ? 0 : std::pow(sdisc, p.dcfr_beta) / (std::pow(sdisc, p.dcfr_beta) + 1.);
+        }
+        // opponent reach from the roots' beliefs, top-down under sigma
+        hipLaunchKernelGGL(forest_root_reach_kernel, dim3((unsigned)((count * H + 255) / 256)), dim3(256), 0, st, f_nodes.p, bel.p,
+                           d_reach.p, count, H, 1 - t);
+        SweepArgs w = sweep_args(f_sigma.p, t);
+        w.sub = f_sub.p;
+        w.act_sub = f_act.p;
+        w.iter = it;
+        for (int lev = D; lev + 1 < nl; ++lev) {
+          w.n0 = ft.lev_off[lev];
+          w.n1 = ft.lev_off[lev + 1];
+          w.level = lev;
+          hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)(((w.n1 - w.n0) * H + 255) / 256)), dim3(256), 0, st, w);
+        }
+        a = args(t);
+        a.sigma = f_sigma.p;
+        a.regrets = f_regrets.p;
+        a.pos = pos;
+        a.neg = neg;
+        a.strat = 1;
+        a.sub = f_sub.p;
+        a.act_sub = f_act.p;
+        a.iter = it;
+        for (int lev = nl - 2; lev >= D; --lev) {
+          level(a, lev);
+          w.n0 = a.n0;
+          w.n1 = a.n1;
+          w.level = lev;
+          hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((w.n1 - w.n0 + 255) / 256)), dim3(256), 0, st, w);
+          hipLaunchKernelGGL(st_value_kernel, grid(a), dim3(256), 0, st, a);
+        }
+        RBL_HIP_CHECK(hipGetLastError());
+        ++steps[t];
+      }
+      // the subgames' sampling strategies: sigma of every edge below depth D (edge = child - 1, children of depth > D are the
+      // tail of the BFS order)
+      const int64_t e0 = ft.lev_off[D + 1] - 1;
+      RBL_HIP_CHECK(hipMemcpyAsync(d_samp.p + e0 * H, f_sigma.p + e0 * H, (size_t)(ft.N - 1 - e0) * H * sizeof(double),
+                                   hipMemcpyDeviceToDevice, st));
+    }
+    accumulate_sample();
+    ++n_samples;
+    sample_seconds += now_s() - t0;
+  }
+  void accumulate_sample() {  // summed_strategy / summed_reach of the repeat in d_samp (recursive_eval.cc:136-160)
     std::vector<double> b(g.H, 1.0 / g.H);
     RBL_HIP_CHECK(hipMemcpyAsync(d_reach.p, b.data(), g.H * sizeof(double), hipMemcpyHostToDevice, st));
     RBL_HIP_CHECK(hipMemcpyAsync(d_val.p, b.data(), g.H * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1136,9 +1400,63 @@ struct StreamSolver {
     }
     RBL_HIP_CHECK(hipGetLastError());
     RBL_HIP_CHECK(hipStreamSynchronize(st));
-    ++n_samples;
-    sample_seconds += now_s() - t0;
   }
+  // ---- report_regrets (recursive_eval.cc:28-53) without the list of dense strategies: the regrets of
+  // compute_immediate_regrets accumulate on the device as the strategies come by
+  void regrets_reset() {
+    RBL_HIP_CHECK(hipSetDevice(device));
+    const size_t eh = (size_t)std::max<int64_t>(1, ft.N - 1) * g.H;
+    if (!d_ir.p) d_ir.alloc(eh);
+    RBL_HIP_CHECK(hipMemsetAsync(d_ir.p, 0, eh * sizeof(double), st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    n_ir = 0;
+  }
+  void regrets_add(const double* sigma, bool round32) {  // one more strategy of the list: both traversers' sweeps
+    if (!d_ir.p) regrets_reset();
+    for (int t = 0; t < 2; ++t) {
+      root_beliefs();
+      SweepArgs w = sweep_args(sigma, t);
+      w.round32 = round32 ? 1 : 0;
+      for (int lev = 0; lev + 1 < nlev(); ++lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(br_reach_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w);
+      }
+      for (int lev = nlev() - 2; lev >= 0; --lev) {
+        w.n0 = ft.lev_off[lev];
+        w.n1 = ft.lev_off[lev + 1];
+        w.level = lev;
+        hipLaunchKernelGGL(terminal_value_kernel, dim3((unsigned)((w.n1 - w.n0 + 255) / 256)), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(ir_value_kernel, dim3((unsigned)(((w.n1 - w.n0) * g.H + 255) / 256)), dim3(256), 0, st, w, d_ir.p);
+      }
+      RBL_HIP_CHECK(hipGetLastError());
+    }
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    ++n_ir;
+  }
+  // first: [n_first][H] immediate regrets of the first nodes (the tool prints 20); sums: {sum over the nodes of depth < depth,
+  // sum over the rest}, each node's vector_sum added in node order as the reference does
+  void regrets_report(int depth, int n_first, double* first, double sums[2]) {
+    if (!n_ir) throw std::runtime_error("regrets_report: no strategy was added");
+    const int H = g.H;
+    hipLaunchKernelGGL(ir_max_kernel, dim3((unsigned)((ft.N * H + 255) / 256)), dim3(256), 0, st, d_bid.p, d_cb.p, d_ir.p, d_val.p,
+                       ft.N, H, g.A, g.liar, (double)n_ir);
+    hipLaunchKernelGGL(ir_node_sum_kernel, dim3((unsigned)((ft.N + 255) / 256)), dim3(256), 0, st, d_val.p, d_reach.p, ft.N, H);
+    RBL_HIP_CHECK(hipGetLastError());
+    std::vector<double> node_sum((size_t)ft.N);
+    RBL_HIP_CHECK(hipMemcpyAsync(node_sum.data(), d_reach.p, node_sum.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    const int64_t nf = std::min<int64_t>(n_first, ft.N);
+    if (first && nf > 0)
+      RBL_HIP_CHECK(hipMemcpyAsync(first, d_val.p, (size_t)nf * H * sizeof(double), hipMemcpyDeviceToHost, st));
+    RBL_HIP_CHECK(hipStreamSynchronize(st));
+    const int64_t split = depth < nlev() ? ft.lev_off[std::max(depth, 0)] : ft.N;  // nodes of depth < `depth` come first (BFS)
+    double top = 0, bottom = 0;
+    for (int64_t n = 0; n < ft.N; ++n) (n < split ? top : bottom) += node_sum[(size_t)n];
+    sums[0] = top;
+    sums[1] = bottom;
+  }
+
   void sampled_final() {
     if (!n_samples) throw std::runtime_error("sampled_final: no repeats were added");
     AccArgs a = acc_args();
@@ -1272,6 +1590,37 @@ int rbl_stream_sampled_add(rbl_stream* s, rbl_engine* e, int seed) {
   return stream_guard([&] {
     if (!s || !e) throw std::runtime_error("null stream solver or engine");
     s->impl.sampled_add(rbl::engine_impl(e), seed);
+  });
+}
+int rbl_stream_sampled_add_root_only(rbl_stream* s, rbl_engine* e, int seed) {
+  return stream_guard([&] {
+    if (!s || !e) throw std::runtime_error("null stream solver or engine");
+    s->impl.sampled_add_root_only(rbl::engine_impl(e), seed);
+  });
+}
+int rbl_stream_regrets_reset(rbl_stream* s) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    s->impl.regrets_reset();
+  });
+}
+int rbl_stream_regrets_add(rbl_stream* s, int which) {
+  return stream_guard([&] {
+    if (!s) throw std::runtime_error("null stream solver");
+    if (which == RBL_GET_LAST) {
+      s->impl.regrets_add(s->impl.d_sigma.p, false);
+    } else if (which == RBL_GET_SAMPLED) {
+      if (!s->impl.n_samples) throw std::runtime_error("rbl_stream_regrets_add: no sampled repeat yet");
+      s->impl.regrets_add(s->impl.d_samp.p, true);
+    } else {
+      throw std::runtime_error("rbl_stream_regrets_add: which must be RBL_GET_LAST or RBL_GET_SAMPLED");
+    }
+  });
+}
+int rbl_stream_regrets_report(rbl_stream* s, int depth, int n_first, double* first, double sums[2]) {
+  return stream_guard([&] {
+    if (!s || !sums) throw std::runtime_error("null stream solver or output");
+    s->impl.regrets_report(depth, n_first, first, sums);
   });
 }
 int rbl_stream_sampled_eval(rbl_stream* s, double exploitability[2], double ev_of_full[2]) {

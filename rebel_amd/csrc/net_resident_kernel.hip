@@ -322,7 +322,9 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   for (int i = tid; i < 256; i += kWaves * 64) {
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-      prm[(l * 3 + 0) * 256 + i] = m.bias[l * 256 + i];
+      // the bias rides in the accumulators' initial value, in the GEMM's own scale (weights are packed times a power of two
+      // S = 1 / inv_scale; the scaling back happens once per row, inside the LayerNorm factor)
+      prm[(l * 3 + 0) * 256 + i] = K0C <= 2 ? m.bias[l * 256 + i] / m.inv_scale[l] : m.bias[l * 256 + i];
       prm[(l * 3 + 1) * 256 + i] = m.ln_w[l * 256 + i];
       prm[(l * 3 + 2) * 256 + i] = m.ln_b[l * 256 + i];
     }
@@ -372,11 +374,18 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   };
 
   f32x4 acc[kOTW][kRT];
-  auto zero_acc = [&]() {
+  // With one or two input chunks the accumulators start at the (scaled) bias of the wave's features; with three or four the
+  // extra live address at the head of the GEMM pushed hipcc into scratch spills (20 bytes per lane), so there the bias is
+  // added in the epilogue as before
+  constexpr bool kBiasInAcc = K0C <= 2;
+  auto init_acc = [&](const float* pl) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot)
+    for (int ot = 0; ot < kOTW; ++ot) {
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (kBiasInAcc) b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) acc[ot][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < kRT; ++rt) acc[ot][rt] = b4;
+    }
   };
 
   // bias + LayerNorm + GELU on the accumulators, in place, and straight into the next layer's B fragments.
@@ -398,12 +407,17 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         if (PROD >= 2) wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
       }
     }
-    f32x4 d[kOTW][kRT];
+    // d = S x (pre-activation): the bias was the accumulators' initial value (init_acc), the 1 / S is part of rs[] below --
+    // no per-element instruction is spent on either (round 4: -1 of 21 VALU instructions per element pair)
+    f32x4 (&d)[kOTW][kRT] = acc;
+    const float post = kBiasInAcc ? inv_s : 1.0f;  // what is left to scale back inside the LayerNorm factor
+    if constexpr (!kBiasInAcc) {
 #pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
+      for (int ot = 0; ot < kOTW; ++ot) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = acc[ot][rt] * inv_s + b4;
+        for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = acc[ot][rt] * inv_s + b4;
+      }
     }
     constexpr float kC = 0.70710678118654752440f;
     float rs[kRT];
@@ -435,15 +449,15 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves]);
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves + 4]);
         const f32x4 t = s0 + s1;
-        const float var = ((t[0] + t[1]) + (t[2] + t[3])) * (1.0f / 256.0f) + m.ln_eps;
-        float y0 = __builtin_amdgcn_rsqf(var);  // v_rsq_f32 (1 ulp) + one Newton step
-        y0 = y0 * __builtin_fmaf(-0.5f * var, y0 * y0, 1.5f);
-        rs[rt] = kC * y0;
+        const float var = ((t[0] + t[1]) + (t[2] + t[3])) * (post * post * (1.0f / 256.0f)) + m.ln_eps;
+        // v_rsq_f32 is accurate to 1 ulp: 6e-8 relative on the LayerNorm factor, far inside the f16x2 split's 4e-7 (the
+        // Newton step of rounds 1-3 was 4 more instructions per row tile, executed by every lane of every wave)
+        rs[rt] = (kC * post) * __builtin_amdgcn_rsqf(var);
       }
     } else {
       lds_barrier();
 #pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) rs[rt] = kC;
+      for (int rt = 0; rt < kRT; ++rt) rs[rt] = kC * post;
     }
     f32x4 g4[kOTW], o4[kOTW];
 #pragma unroll
@@ -550,7 +564,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 1: staged
 
     // -------------------------------------------------------------- layer 0
-    zero_acc();
+    init_acc(prm);
     gemm_resident<K0C, 0, K0C, kPF, PROD>(th, tl, th, tl, X, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     // The streamed k-steps of the hidden layer take over registers of the layer-0 weights (dead from here on): the first kEarly
@@ -579,7 +593,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 4: L0 epilogue
 
     // -------------------------------------------------------------- hidden layer, weights from registers
-    zero_acc();
+    init_acc(prm + 768);
     if constexpr (kTail == 0)
       gemm_resident<kRes, 0, 1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc);
     else

@@ -21,7 +21,7 @@ Not reproduced: strategy dumps, oracle-net mode.
 
 `--stream`: the same tool with every full-tree array edge-indexed in HBM (rbl_stream_*, eval_stream.hip) instead of dense
 [N][H][A] host arrays -- the only way to run it at 2 dice x 6 faces (33.5 M nodes: 241 GB dense, 9.7 GB edge-indexed per
-strategy).  CFR only, no --root_only, no regret reports; the numbers are bit-identical to the dense path where both run
+strategy).  CFR only (with or without --root_only, with or without the regret reports); the numbers are bit-identical to the dense path where both run
 (tests/test_eval_parity.py::test_stream_sampled_repeats_bit_exact).
 """
 import argparse
@@ -72,7 +72,7 @@ def main_stream(a):
 
     from rebel_amd import capi
 
-    assert a.cfr and not a.root_only, "--stream: CFR solvers only, no --root_only"
+    assert a.cfr, "--stream: CFR solvers only"
     d, f = a.num_dice, a.num_faces
     base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear, use_cfr=True, optimistic=a.optimistic)
     t0 = time.perf_counter()
@@ -81,12 +81,27 @@ def main_stream(a):
     print(f"Tree of depth {s.A} has {s.nodes} nodes")
     print("##############################################\n##### Solving the game for the full tree #####\n"
           "##############################################")
+    want_regrets = a.print_regret or a.print_regret_summary
+
+    def regret_report(first, sums):  # report_regrets, recursive_eval.cc:28-53, from the regrets accumulated on the device
+        out = ""
+        if a.print_regret:
+            out += "\tRegrets: " + "".join(" ".join("%.6f" % x for x in row) + " | " for row in first) + "\n"
+        if a.print_regret_summary:
+            out += "\tRegrets (depth<=%d)/rest: %.6f/%.6f" % (a.mdp_depth, sums[0], sums[1])
+        return out
+
+    if want_regrets:
+        s.regrets_reset()
     for it in range(a.subgame_iters):
         s.step(1)
+        if it % 2 == 0 and want_regrets:
+            s.regrets_add(capi.GET_LAST)  # the tool lists the sampling strategy after every even iteration (:285-287)
         if ((it + 1) & it) == 0 or it + 1 == a.subgame_iters:
             ex = s.exploitability()
             print("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e" % (it + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2), flush=True)
     print(f"Full FP exploitability: {(ex[0] + ex[1]) / 2:.6f} ({ex[0]:.6f},{ex[1]:.6f})")
+    print(regret_report(*s.regrets_report(a.mdp_depth)) if want_regrets else "")
     t_full = time.perf_counter() - t0
     results = [("net", a.net), ("full_tree", "%.6f" % ((ex[0] + ex[1]) / 2))]
     results_ev = [("net", a.net), ("full_tree", "%.6f" % 0.0)]  # compute_ev2 of a strategy against itself: (x - x) / 2
@@ -98,12 +113,17 @@ def main_stream(a):
         eng = capi.Engine(d, f, capi.make_params(max_depth=a.mdp_depth, **base), max_lanes=a.max_lanes, device=a.device)
         load_net(eng, a.net)
         t1 = time.perf_counter()
+        if want_regrets:
+            s.regrets_reset()  # a new list for this section (:343)
         for sid in range(max(a.num_repeats, 0)):
-            s.sampled_add(eng, sid)
+            s.sampled_add(eng, sid, root_only=a.root_only)
+            if want_regrets:
+                s.regrets_add(capi.GET_SAMPLED)
             if ((sid + 1) & sid) == 0 or sid + 1 == a.num_repeats:
                 ex, ev = s.sampled_eval()
                 print("%5d: %.6f (%.6f,%.6f)\tEV of full: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1],
-                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1]), flush=True)
+                                                                          (ev[0] + ev[1]) / 2, ev[0], ev[1])
+                      + (regret_report(*s.regrets_report(a.mdp_depth)) if want_regrets else ""), flush=True)
                 results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
                 results_ev.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
         t_rep = time.perf_counter() - t1
@@ -148,15 +168,36 @@ def main():
     full = capi.Engine(d, f, capi.make_params(max_depth=100000, **base), max_lanes=1, device=a.device)
     full.set_net_zero()
     H = full.H
+    want_regrets = a.print_regret or a.print_regret_summary
+
+    def regret_lines(reg, total_nodes):  # report_regrets, recursive_eval.cc:28-53 (the tool prints fixed, 6 decimals: :208)
+        out = ""
+        if a.print_regret:
+            out += "\tRegrets: " + "".join(" ".join("%.6f" % x for x in reg[n]) + " | " for n in range(min(20, total_nodes))) + "\n"
+        return out
+
     full.reset([-1], [0], np.full((1, 2, H), 1.0 / H))
+    full_list = []  # the sampling strategy after every even iteration (:285-287); only kept when a report is asked for
     for it in range(a.subgame_iters):
         full.step(it % 2)
+        if it % 2 == 0 and a.cfr and want_regrets:
+            full_list.append(full.get(0, capi.GET_LAST))
         if ((it + 1) & it) == 0 or it + 1 == a.subgame_iters:
             ex = capi.exploitability2(d, f, full.get(0, capi.GET_AVERAGE), a.device)
             print("Iter=%8d exploitabilities=(%.3e, %.3e) sum=%.3e" % (it + 1, ex[0], ex[1], (ex[0] + ex[1]) / 2))
     full_strategy = full.get(0, capi.GET_AVERAGE)
     ex = capi.exploitability2(d, f, full_strategy, a.device)
     print(f"Full FP exploitability: {(ex[0] + ex[1]) / 2:.6f} ({ex[0]:.6f},{ex[1]:.6f})")
+    if a.cfr:  # report_regrets + "\n" (:302-306): an empty line when no report is asked for
+        line = ""
+        if full_list:
+            reg = capi.immediate_regrets(d, f, np.stack(full_list), a.device)
+            line = regret_lines(reg, len(tree))
+            if a.print_regret_summary:
+                top = sum(reg[n].sum() for n in range(len(tree)) if tree[n][5] < a.mdp_depth)
+                rest = sum(reg[n].sum() for n in range(len(tree)) if tree[n][5] >= a.mdp_depth)
+                line += "\tRegrets (depth<=%d)/rest: %.6f/%.6f" % (a.mdp_depth, top, rest)
+        print(line)
     results = [("net", a.net), ("full_tree", "%.6f" % ((ex[0] + ex[1]) / 2))]
     ev = capi.ev2(d, f, full_strategy, full_strategy, a.device)
     results_ev = [("net", a.net), ("full_tree", "%.6f" % ((ev[0] + ev[1]) / 2))]
@@ -174,12 +215,11 @@ def main():
             if not strategy_list or not (a.print_regret or a.print_regret_summary):
                 return ""
             reg = capi.immediate_regrets(d, f, np.stack(strategy_list), a.device)
-            out = ""
-            if a.print_regret:
-                out += "\tRegrets: " + "".join(" ".join("%g" % x for x in reg[n]) + " | " for n in range(min(20, len(reg)))) + "\n"
+            out = regret_lines(reg, len(tree))
             if a.print_regret_summary:
                 top = sum(reg[n].sum() for n in range(len(tree)) if tree[n][5] < a.mdp_depth)
-                out += "\tRegrets (depth<=%d)/rest: %g/%g" % (a.mdp_depth, top, reg.sum() - top)
+                rest = sum(reg[n].sum() for n in range(len(tree)) if tree[n][5] >= a.mdp_depth)
+                out += "\tRegrets (depth<=%d)/rest: %.6f/%.6f" % (a.mdp_depth, top, rest)
             return out
 
         for sid in range(max(a.num_repeats, 0)):

@@ -2,6 +2,8 @@
 tool oracle/_ref/recursive_eval (csrc/liars_dice/recursive_eval.cc, built by oracle/Makefile `ref`) for
   (a) --net zero --cfr                       (full-tree solve only: the tool cannot repeat with the zero net), and
   (b) --net <TorchScript Net2, seed 1234> --mdp_depth 2 --num_repeats 4 --cfr
+  (c) --net zero --cfr --print_regret --print_regret_summary   (the regret report of the full-tree section; round 4: made in
+      the build container -- it needs no GPU -- and merged into the json: `make_recursive_eval_golden.py --only-regrets`)
 on 1 die x 4 faces.  tests/test_eval_parity.py::test_recursive_eval_tool_vs_reference_binary runs scripts/recursive_eval.py
 with the same arguments and compares the XXX / YYY lines (scripts/eval_all.py:100-104 parses them).
 The reference tool loads a TorchScript net on "cuda" first (recursive_eval.cc:316, real_net.cc:130-132), so (b) needs a
@@ -35,6 +37,13 @@ def run(args):
 
 
 def main():
+    if "--only-regrets" in sys.argv:  # merge case (c) into the committed json without touching the GPU-made cases
+        path = os.path.join(ROOT, "tests", "golden", "recursive_eval_1d4f.json")
+        golden = json.load(open(path))
+        golden["zero_regrets"] = run(COMMON + ["--subgame_iters", "64", "--net", "zero", "--print_regret", "--print_regret_summary"])
+        json.dump(golden, open(path, "w"), indent=1)
+        print("\n".join(golden["zero_regrets"]["stdout"][-10:]))
+        return
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.manual_seed(1234)
@@ -49,6 +58,8 @@ def main():
         torch.jit.script(net).save(pt)
         golden = dict(
             zero=run(COMMON + ["--subgame_iters", "256", "--net", "zero"]),
+            # report_regrets of the full-tree section (recursive_eval.cc:28-53, 285-306): needs no GPU
+            zero_regrets=run(COMMON + ["--subgame_iters", "64", "--net", "zero", "--print_regret", "--print_regret_summary"]),
             net=run(COMMON + ["--subgame_iters", "32", "--num_repeats", "4", "--num_threads", "1", "--net", pt]))
     golden["net"]["args"][-1] = "tests/golden/recursive_eval_net_1d4f.npz"
     golden["net"]["xxx"]["net"] = golden["net"]["yyy"]["net"] = "tests/golden/recursive_eval_net_1d4f.npz"

