@@ -172,7 +172,8 @@ def test_recursive_eval_tool(tmp_path):
     assert d["net"] == "zero" and float(d["full_tree"]) < 0.05
     assert float(d["repeated toleaf 8"]) < float(d["repeated toleaf 1"])
     assert "Iter=      64" in r.stdout
-    assert r.stdout.count("Regrets (depth<=100)/rest: ") == 4  # report_regrets at 1, 2, 4, 8 repeats (recursive_eval.cc:41-52)
+    # report_regrets after the full-tree solve (recursive_eval.cc:302-306) and at 1, 2, 4, 8 repeats (:374-377)
+    assert r.stdout.count("Regrets (depth<=100)/rest: ") == 5
     ev = json.loads([l for l in r.stdout.splitlines() if l.startswith("YYY ")][-1][4:])
     assert set(ev) == set(d) and abs(float(ev["full_tree"])) < 1e-6  # EV of the full-tree strategy against itself
 
