@@ -1060,6 +1060,7 @@ struct StreamSolver {
   int n_ir = 0;
   DevBuf<double> f_sigma, f_regrets;  // forest solve (root_only repeats): sigma and regrets of the subgames below the root's
   DevBuf<int32_t> f_sub, f_act, f_nodes;
+  int f_sub_depth = -1;  // max_depth the subtree map f_sub was built for
   int n_samples = 0;
   double sample_seconds = 0;
   int iter = 0, num_steps[2] = {0, 0};
@@ -1307,6 +1308,9 @@ struct StreamSolver {
         f_sigma.alloc(eh);
         f_regrets.alloc(eh);
         f_sub.alloc((size_t)ft.N);
+      }
+      if (f_sub_depth != D) {  // the subtree map belongs to one root-subgame depth (an engine with another max_depth: rebuild)
+        f_sub_depth = D;
         // subtree ids: the nodes of depth D number themselves (terminals included: they have no descendants), top-down
         for (int lev = D; lev + 1 <= nl; ++lev) {
           const int64_t n0 = ft.lev_off[lev], n1 = ft.lev_off[lev + 1];
