@@ -444,15 +444,29 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       const int rtp = ((g & 1) << 1) | (g >> 1);
       S[(rtp * 16 + j) * kWaves + wave] = a01 + a23;
       lds_barrier();
-#pragma unroll
-      for (int rt = 0; rt < kRT; ++rt) {
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves]);
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(&S[(rt * 16 + j) * kWaves + 4]);
+      // A lane needs the factors of four rows (row j of every row tile).  Until round 4 every lane derived all four from the
+      // partial sums (2 LDS reads + 11 VALU each, the same 64 results computed by all 64 lanes of all 8 waves); now lane
+      // (j, g) derives the ONE of row tile g and the four lane groups exchange theirs with three lane swaps: swap16 of two
+      // copies leaves [v0, v0, v2, v2] / [v1, v1, v3, v3] in the rows of the two registers, swap32 of each with a copy of
+      // itself [v0 x4], [v2 x4] and [v1 x4], [v3 x4] (semantics: the variance reduction above).
+      {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(&S[(g * 16 + j) * kWaves]);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(&S[(g * 16 + j) * kWaves + 4]);
         const f32x4 t = s0 + s1;
         const float var = ((t[0] + t[1]) + (t[2] + t[3])) * (post * post * (1.0f / 256.0f)) + m.ln_eps;
         // v_rsq_f32 is accurate to 1 ulp: 6e-8 relative on the LayerNorm factor, far inside the f16x2 split's 4e-7 (the
-        // Newton step of rounds 1-3 was 4 more instructions per row tile, executed by every lane of every wave)
-        rs[rt] = (kC * post) * __builtin_amdgcn_rsqf(var);
+        // Newton step of rounds 1-3 was 4 more instructions per row tile)
+        const float mine = (kC * post) * __builtin_amdgcn_rsqf(var);
+        float e0, e1, e2, e3;
+        asm("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %4\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1\n\t"
+            "v_mov_b32 %2, %0\n\tv_mov_b32 %3, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\t"
+            "v_permlane32_swap_b32 %1, %3\n\ts_nop 1"
+            : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+            : "v"(mine));
+        rs[0] = e0;
+        rs[1] = e1;
+        rs[2] = e2;
+        rs[3] = e3;
       }
     } else {
       lds_barrier();
