@@ -259,12 +259,20 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   }
   constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
   constexpr int kWoF4 = kKS * 2 * 64;             // one output tile's weight fragments (16 KB)
-  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4];
+  // kEarlyStage: the next group's queries are turned into B fragments in a region of their own (Xq) while this group's
+  // hidden GEMM drains, so a group starts with its layer-0 GEMM instead of a staging phase and a barrier (round 4: ~830 of
+  // 17.7 k cycles per group).  With three or four input chunks the region (24 / 32 KB) and the longer live ranges are not
+  // worth it: those shapes stage at the head of the group as before, into the activation image itself.
+  constexpr bool kEarlyStage = K0C <= 2;
+  constexpr int kQImageBytes = kEarlyStage ? K0C * 2 * kRT * 64 * 16 : 0;
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes];
   f32x4* X = reinterpret_cast<f32x4*>(smem);                 // [ks][hi,lo][row tile][lane] B fragments
   unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
   float* S = reinterpret_cast<float*>(smem + kImageBytes);   // [row][wave] sums of squares
   f32x4* P = reinterpret_cast<f32x4*>(S + kRows * kWaves);   // [wave][row tile][lane] partial outputs (k slice of a wave)
   float* prm = reinterpret_cast<float*>(P + kWaves * kRT * 64);  // [layer][bias, gamma, beta'][256], output bias
+  f32x4* Xq = kEarlyStage ? reinterpret_cast<f32x4*>(prm + kParamFloats) : X;  // B fragments of the query rows (layer 0's input)
+  unsigned long long* Xq8 = reinterpret_cast<unsigned long long*>(Xq);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
   const int lane0 = tid & 63;
   int lane = lane0, j = lane0 & 15, g = lane0 >> 4;
@@ -421,6 +429,27 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     }
     constexpr float kC = 0.70710678118654752440f;
     float rs[kRT];
+    // gamma and beta / sqrt2 of this lane's features: requested BEFORE the LayerNorm barrier (the barrier is a compiler fence
+    // for LDS accesses), and d is multiplied by gamma while the wave would otherwise wait for the row statistics: the 16
+    // multiplies per layer that used to form gamma x rs AFTER the barrier are off the critical path (same instruction count)
+    // (With three or four input chunks the longer live ranges of gamma / beta cost scratch spills: those shapes fetch and
+    // multiply after the barrier, as before.)
+    constexpr bool kGammaEarly = K0C <= 2;
+    f32x4 g4[kOTW], o4[kOTW];
+    auto fetch_gamma_beta = [&]() {
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot) {
+        g4[ot] = *reinterpret_cast<const f32x4*>(pl + 256 + 32 * wave + 16 * ot + 4 * g);
+        o4[ot] = *reinterpret_cast<const f32x4*>(pl + 512 + 32 * wave + 16 * ot + 4 * g);  // beta / sqrt2
+      }
+    };
+    auto times_gamma = [&]() {
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot)
+#pragma unroll
+        for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = d[ot][rt] * g4[ot];
+    };
+    if constexpr (kGammaEarly) fetch_gamma_beta();
     if constexpr (LN) {
       // weights and biases are centred over the output features on the host: d has zero row mean, only the variance is left
       float q[kRT];
@@ -443,6 +472,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a01), "+v"(a23));
       const int rtp = ((g & 1) << 1) | (g >> 1);
       S[(rtp * 16 + j) * kWaves + wave] = a01 + a23;
+      if constexpr (kGammaEarly) times_gamma();
       lds_barrier();
       // A lane needs the factors of four rows (row j of every row tile).  Until round 4 every lane derived all four from the
       // partial sums (2 LDS reads + 11 VALU each, the same 64 results computed by all 64 lanes of all 8 waves); now lane
@@ -469,16 +499,12 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         rs[3] = e3;
       }
     } else {
+      if constexpr (kGammaEarly) times_gamma();
       lds_barrier();
 #pragma unroll
       for (int rt = 0; rt < kRT; ++rt) rs[rt] = kC * post;
     }
-    f32x4 g4[kOTW], o4[kOTW];
-#pragma unroll
-    for (int ot = 0; ot < kOTW; ++ot) {
-      g4[ot] = *reinterpret_cast<const f32x4*>(pl + 256 + 32 * wave + 16 * ot + 4 * g);
-      o4[ot] = *reinterpret_cast<const f32x4*>(pl + 512 + 32 * wave + 16 * ot + 4 * g);  // beta / sqrt2
-    }
+    if constexpr (!kGammaEarly) fetch_gamma_beta();
 #pragma unroll
     for (int rt = 0; rt < kRT; ++rt) {
       f16x2 h[4], l[4];
@@ -490,7 +516,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
           h[2 * ot + h2] = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[ot][rt][2 * h2] * rs[rt], d[ot][rt][2 * h2 + 1]));
           l[2 * ot + h2] = h[2 * ot + h2];
 #else
-          const f32x2 a = f32x2{g4[ot][2 * h2], g4[ot][2 * h2 + 1]} * splat2(rs[rt]);
+          const f32x2 a = kGammaEarly ? splat2(rs[rt]) : f32x2{g4[ot][2 * h2], g4[ot][2 * h2 + 1]} * splat2(rs[rt]);
           const f32x2 y = gelu_z(fma2(f32x2{d[ot][rt][2 * h2], d[ot][rt][2 * h2 + 1]}, a,
                                       f32x2{o4[ot][2 * h2], o4[ot][2 * h2 + 1]}));
           if (PROD == 3) {
@@ -545,8 +571,12 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   fetch_queries(blockIdx.x);
   __syncthreads();  // parameter copies visible
 
-  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+  const int stamp_group = m.stagger;  // developer aid (RBL_MLP_STAGGER): which of the workgroup's groups the stamps describe
+  int group_no = 0;
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x, ++group_no) {
     const int64_t row0 = (int64_t)grp * kRows;
+    dbg = group_no == stamp_group ? dbg_end : nullptr;  // (0: the first group, which includes the cold start)
+    dbg_k = 0;
     // lane-derived indices are re-derived every group: hoisted out of the loop, the dozens of LDS / global addresses built
     // from them stay live across all phases and push the 256-VGPR budget (128 of it weights) into scratch spills
     lane = lane0;
@@ -555,7 +585,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     g = lane >> 4;
     RBL_NSTAMP();  // 0
     // -------------------------------------------------------------- fetched queries -> f16x2 B fragments (8 bytes each)
-    {
+    auto stage_queries = [&]() {
       const int rt = wave >> 1, half = wave & 1;
 #pragma unroll
       for (int ks = 0; ks < K0C; ++ks) {
@@ -569,17 +599,20 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
           l0 = l1 = f16x2{(_Float16)0.f, (_Float16)0.f};
         }
         const f16x4 hh = f16x4{h0[0], h0[1], h1[0], h1[1]}, ll = f16x4{l0[0], l0[1], l1[0], l1[1]};
-        X8[(((ks * 2 + 0) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, hh);
-        if (PROD == 3) X8[(((ks * 2 + 1) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, ll);
+        Xq8[(((ks * 2 + 0) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, hh);
+        if (PROD == 3) Xq8[(((ks * 2 + 1) * kRT + rt) * 64 + lane) * 2 + half] = __builtin_bit_cast(unsigned long long, ll);
       }
+    };
+    if (!kEarlyStage || group_no == 0) {
+      stage_queries();
+      lds_barrier();
+      fetch_queries(grp + gridDim.x);  // in flight until the next group is staged
     }
-    lds_barrier();
-    fetch_queries(grp + gridDim.x);  // in flight until the next group is staged
     RBL_NSTAMP();  // 1: staged
 
     // -------------------------------------------------------------- layer 0
     init_acc(prm);
-    gemm_resident<K0C, 0, K0C, kPF, PROD>(th, tl, th, tl, X, lane, acc);
+    gemm_resident<K0C, 0, K0C, kPF, PROD>(th, tl, th, tl, Xq, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     // The streamed k-steps of the hidden layer take over registers of the layer-0 weights (dead from here on): the first kEarly
     // of them are requested BEFORE the layer-0 epilogue, whose ~6 k cycles cover the L2 round trips; the rest is requested
@@ -613,6 +646,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     else
       gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(IE{}, IT{}, I0{}); });
     RBL_NSTAMP();  // 5: hidden gemm
+    if (kEarlyStage) {
+      // the next group's queries (requested a whole group ago) become B fragments now: Xq was last read by this group's layer-0
+      // GEMM, two barriers back, and the two barriers of the epilogue below order these stores before the next group's
+      // layer-0 GEMM reads them.  The older wave of a SIMD gets here ~2.5 k cycles before its partner: this is idle time
+      stage_queries();
+      fetch_queries(grp + 2 * (int)gridDim.x);
+    }
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
     RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
@@ -696,7 +736,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 8: output layer
     if constexpr (kW0Late)
       if (grp + (int)gridDim.x < n_groups) fetch_w0();
-    dbg = nullptr;  // stamps describe the first group of each workgroup
   }
   if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
 #undef RBL_NSTAMP
