@@ -788,6 +788,9 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.snapshot = d_snapshot_.p;
   a.root_mean = d_root_mean_.p;
   a.queries = d_queries_.p;
+  // (qsplit_ changes only when the net KIND changes -- set_net_* under net_mutex_, after sync() has drained both streams.  A
+  // weight refresh from another thread, ModelLocker::updateModel, keeps the kind and so the layout; switching kinds in the middle
+  // of a solve is for the thread that drives the solve: tests and C callers)
   a.q_dyn = qsplit_ ? d_qdyn_.p : nullptr;
   a.q_dyn_stride = q_ds_;
   a.values = d_values_.p;
