@@ -263,6 +263,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // hidden GEMM drains, so a group starts with its layer-0 GEMM instead of a staging phase and a barrier (round 4: ~830 of
   // 17.7 k cycles per group).  With three or four input chunks the region (24 / 32 KB) and the longer live ranges are not
   // worth it: those shapes stage at the head of the group as before, into the activation image itself.
+  // (Tried for four chunks too, staging before the hidden epilogue or right after the layer-0 epilogue: the 16 more live floats
+  // cost 20 bytes of scratch per lane in the 2 dice x 6 faces instantiation either way.)
   constexpr bool kEarlyStage = K0C <= 2;
   constexpr int kQImageBytes = kEarlyStage ? K0C * 2 * kRT * 64 * 16 : 0;
   __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes];
