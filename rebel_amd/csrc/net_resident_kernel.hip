@@ -264,7 +264,10 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // 17.7 k cycles per group).  With three or four input chunks the region (24 / 32 KB) and the longer live ranges are not
   // worth it: those shapes stage at the head of the group as before, into the activation image itself.
   // (Tried for four chunks too, staging before the hidden epilogue or right after the layer-0 epilogue: the 16 more live floats
-  // cost 20 bytes of scratch per lane in the 2 dice x 6 faces instantiation either way.)
+  // cost 20 bytes of scratch per lane in the 2 dice x 6 faces instantiation either way.
+  // After the hidden epilogue instead (nothing in flight, accumulators dead) one resident weight fragment is spilled and the
+  // stamped group is no shorter: at n_in = 99 the 3.9 k cycles of the head phase are the ISSUE of the next rows' 16 unaligned
+  // loads per thread and the staging itself, not a wait -- they move, they do not shrink.)
   constexpr bool kEarlyStage = K0C <= 2;
   constexpr int kQImageBytes = kEarlyStage ? K0C * 2 * kRT * 64 * 16 : 0;
   __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes];
