@@ -557,12 +557,21 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // the rows themselves: one item per element, consecutive threads = consecutive floats of the exchange buffer.
     // (x + eps) / s is hipcc's f64 division sequence minus v_div_scale / v_div_fixup, the identity here
     // (1e-80 <= x + eps <= s <= H + 1)
-    float* gq = a.queries + (size_t)row_off * Q;
-    // the head of a row: player to move, traverser, one-hot last bid
-    for (int i = tid; i < L * (2 + A); i += NT) {
-      const int k = i / (2 + A), j = i - k * (2 + A);
-      const int rec = t_qrec[k];
-      gq[(size_t)k * Q + j] = j == 0 ? (float)((rec >> 18) & 1) : (j == 1 ? (float)a.next_trav : (j - 2 == (rec >> 19) ? 1.0f : 0.0f));
+    // Split layout (a.q_dyn; engine.hip "Split query layout", round 4 for this kernel): what changes between iterations -- the
+    // traverser flag and the two reach vectors -- goes to contiguous 16-byte aligned rows [rows][q_dyn_stride] that the value
+    // net reads with aligned 16-byte loads (at n_in = 99 the canonical rows cost the net 16 unaligned loads per thread and
+    // group); player and last-bid one-hot were split off once per epoch behind the solver-init launch and are not touched here
+    float* gq = a.q_dyn ? a.q_dyn + (size_t)row_off * a.q_dyn_stride : a.queries + (size_t)row_off * Q;
+    const int qstride = a.q_dyn ? a.q_dyn_stride : Q, qreach = a.q_dyn ? 1 : 2 + A;
+    if (a.q_dyn) {
+      for (int k = tid; k < L; k += NT) gq[(size_t)k * qstride] = (float)a.next_trav;
+    } else {
+      // the head of a row: player to move, traverser, one-hot last bid
+      for (int i = tid; i < L * (2 + A); i += NT) {
+        const int k = i / (2 + A), j = i - k * (2 + A);
+        const int rec = t_qrec[k];
+        gq[(size_t)k * Q + j] = j == 0 ? (float)((rec >> 18) & 1) : (j == 1 ? (float)a.next_trav : (j - 2 == (rec >> 19) ? 1.0f : 0.0f));
+      }
     }
     // the two reach vectors: a pair of hands of BOTH players per thread and row
     if (in_grid) {
@@ -584,7 +593,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 #pragma unroll
         for (int u = 0; u < kU; ++u)
           if (kb + u * R < L) {
-            float* row = gq + (size_t)(kb + u * R) * Q + 2 + A + 2 * h2;
+            float* row = gq + (size_t)(kb + u * R) * qstride + qreach + 2 * h2;
 #pragma unroll
             for (int wh = 0; wh < 2; ++wh) {
               const bool acted = wh == pm[u];

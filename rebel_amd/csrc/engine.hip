@@ -326,7 +326,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   // Split query layout (cfr_kernels.h): the one-wavefront CFR kernel writes only what changes per iteration, as contiguous
   // rows; the resident forward reads (dynamic row | static row) as its input, layer 0 packed for that column order.
   const int ds = (1 + 2 * g_.H + 3) & ~3, ss = (1 + g_.A + 3) & ~3;
-  const bool split = wave_ok_ && p_.use_cfr && tile == 5 && env_int("RBL_QSPLIT", 1) != 0 &&
+  const bool split = (wave_ok_ || (flat_ok_ && rows_global_ok_)) && p_.use_cfr && tile == 5 && env_int("RBL_QSPLIT", 1) != 0 &&
                      mlp_resident_supported(w.n_layers, ds + ss, w.n_hidden, w.n_out);
   std::vector<float> w0v;
   std::vector<const float*> wv(w.w, w.w + w.n_layers);
@@ -844,7 +844,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
     if (is_step) last_cfr_kernel_ = which;
     if (qsplit_) {
       if (mode == kModeInit || mode == kModeQueries) split_part_queries(part, st);  // the generic kernel wrote canonical rows
-      else if (mode == kModeStep && which == 2) q_canon_stale_ = true;              // the wave kernel wrote dynamic rows only
+      else if (mode == kModeStep && (which == 2 || which == 4)) q_canon_stale_ = true;  // the wave / flat kernel wrote dynamic rows only
     }
     const bool sampled = is_step && time_end(0, st);
     RBL_HIP_CHECK(hipGetLastError());

@@ -241,9 +241,9 @@ def test_queries_bit_exact_first_iteration(port):
     assert np.array_equal(e.queries(), seen[0])
 
 
-@pytest.mark.parametrize("d,f", [(1, 6), (1, 4), (2, 3)])
+@pytest.mark.parametrize("d,f", [(1, 6), (1, 4), (2, 3), (2, 6)])
 def test_split_query_layout_equals_canonical(d, f, monkeypatch, port):
-    """With the fused MLP net the one-wavefront CFR kernel writes only the dynamic part of the query rows, contiguously
+    """With the fused MLP net the one-wavefront CFR kernel (and, since round 4, the 2 dice x 6 faces flat kernel) writes only the dynamic part of the query rows, contiguously
     (CfrArgs::q_dyn), and the net reads (dynamic row | static row): the canonical [rows, Q] matrix rebuilt from them equals the
     matrix of the canonical path (RBL_QSPLIT=0), of a zero-net engine and of the oracle bit for bit.  The net here has a zero
     output layer, so the two layouts' different summation orders cannot leak into the CFR state."""
