@@ -18,4 +18,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o fet
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o write -- $CMD > $O/write.log 2>&1
 cd $R
 python3 scripts/pmc_summary.py $O $TAG
+# keep the summaries, drop the raw traces (tens of MB per pass: gpurun merges at most 64 MiB back)
+cp $O/kt/kt_kernel_stats.csv $O/${TAG}_rocprofv3_kernel_stats.csv 2>/dev/null
+if [ -z "$KEEP_RAW" ]; then rm -rf $O/kt $O/fetch $O/write; fi
 ls -la $O | head -30
