@@ -808,6 +808,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.optimistic = p_.optimistic ? 1 : 0;
   a.br_out = d_br_.p;
   a.dbg = cfr_dbg_ ? d_dbg_.p : nullptr;
+  LaunchTimingDisarm disarm_on_exit;
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int l0 = part_lane_[part], cnt = part_lane_[part + 1] - l0;
@@ -874,6 +875,7 @@ void Engine::run_net() {
     return;
   }
   const int Q = g_.query_size(), H = g_.H;
+  LaunchTimingDisarm disarm_on_exit;
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int64_t r0 = part_row_[part], nr = part_row_[part + 1] - r0;

@@ -18,6 +18,12 @@ struct LaunchTimingSlot {
 };
 extern thread_local LaunchTimingSlot tl_launch_timing;
 
+// Scope guard of the code that arms the slot: whatever happens between arming and the launch (an exception from a failed
+// launch, an early return), the slot does not stay armed with events of an engine that may be gone by the next launch.
+struct LaunchTimingDisarm {
+  ~LaunchTimingDisarm() { tl_launch_timing = LaunchTimingSlot{}; }
+};
+
 }  // namespace rbl
 
 // launch `kernel`; when the calling thread armed the timing slot, bind its events to this dispatch
