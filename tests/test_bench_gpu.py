@@ -46,6 +46,12 @@ def test_bench_force_dist_single_rank_rccl():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     d = _run(["--force-dist", "--no-extra-legs"], env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
+    # the per-GPU figures travel through an RCCL all_gather of device tensors (rebel_amd/sharding.py: gather_ranks)
+    pg = d["per_gpu"]
+    assert pg["ranks_seen_by_rccl"] == 1 and pg["backend"] == "nccl" and len(pg["ranks"]) == 1
+    r0 = pg["ranks"][0]
+    assert r0["rank"] == 0 and r0["gpu"] == 0 and abs(r0["value"] - d["value"]) < 1e-3 * d["value"]
+    assert abs(r0["cfr_frac_hbm"] - d["roofline_cfr"]["frac"]) < 1e-9 and abs(r0["net_frac_mfma"] - d["roofline"]["frac"]) < 1e-9
 
 
 def test_bench_gpus_flag_refuses_more_gpus_than_the_box_has():
