@@ -576,41 +576,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   fetch_queries(blockIdx.x);
   __syncthreads();  // parameter copies visible
 
-  constexpr bool kDeferOutput = NOTV == 1 && kEarlyStage;
-  // Output layer, last step: the eight waves' k slices of (tile, row tile) are summed, scaled, biased and stored by waves 0 ..
-  // n_reg * 4 - 1.  kDeferOutput (one output tile, one or two input chunks): those are the OLDER waves of their SIMDs, which
-  // reach the next group's hidden-layer LayerNorm barrier ~2.5 k cycles before their partners (the matrix pipe serves the
-  // older wave first) -- so the sum of group n is taken THERE, in idle time, instead of on the critical path between two
-  // groups (~0.75 k cycles of 17 k).  P holds group n's partials until the barrier that follows; the last group of a
-  // workgroup is summed after the loop.
-  auto reduce_output = [&](int64_t row0) {
-      const int n_reg = m.out_tiles < NOT ? m.out_tiles : NOT;
-      for (int p = wave; p < n_reg * kRT; p += kWaves) {
-        const int t = p >> 2, rt = p & 3;
-        const f32x4* pt = t == 0 ? P : X + (size_t)(t - 1) * kWaves * kRT * 64;
-        f32x4 o = pt[(0 * kRT + rt) * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) o += pt[(w * kRT + rt) * 64 + lane];
-        // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
-        int r_in = rt * 16 + j, col = t * 16 + 4 * g;
-        const int n_out = m.n_out;
-        asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
-        const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
-        float* og = out + row0 * n_out;
-        const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
-        if (r_in < rows_here) {
-          if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
-            f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
-            if (col + 1 < n_out) p2[0] = f32x2{r4[0], r4[1]};
-            if (col + 3 < n_out) p2[1] = f32x2{r4[2], r4[3]};
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
-          }
-        }
-      }
-  };
   const int stamp_group = m.stagger;  // developer aid (RBL_MLP_STAGGER): which of the workgroup's groups the stamps describe
   int group_no = 0;
   for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x, ++group_no) {
@@ -692,7 +657,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       // layer-0 GEMM reads them.  The older wave of a SIMD gets here ~2.5 k cycles before its partner: this is idle time
       stage_queries();
       fetch_queries(grp + 2 * (int)gridDim.x);
-      if (kDeferOutput && group_no > 0) reduce_output(row0 - (int64_t)gridDim.x * kRows);  // the previous group of this workgroup
     }
     RBL_NSTAMP();  // 6
     epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
@@ -703,7 +667,34 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       if (grp + (int)gridDim.x < n_groups) fetch_w0();
 
     // -------------------------------------------------------------- register tiles: sum the 8 k slices of (tile, row tile)
-    if constexpr (!kDeferOutput) reduce_output(row0);
+    {
+      const int n_reg = m.out_tiles < NOT ? m.out_tiles : NOT;
+      for (int p = wave; p < n_reg * kRT; p += kWaves) {
+        const int t = p >> 2, rt = p & 3;
+        const f32x4* pt = t == 0 ? P : X + (size_t)(t - 1) * kWaves * kRT * 64;
+        f32x4 o = pt[(0 * kRT + rt) * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) o += pt[(w * kRT + rt) * 64 + lane];
+        // 32-bit lane offsets from a scalar group base (64-bit per-lane row indices were being spilled)
+        int r_in = rt * 16 + j, col = t * 16 + 4 * g;
+        const int n_out = m.n_out;
+        asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
+        const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
+        float* og = out + row0 * n_out;
+        const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
+        if (r_in < rows_here) {
+          if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
+            f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
+            if (col + 1 < n_out) p2[0] = f32x2{r4[0], r4[1]};
+            if (col + 3 < n_out) p2[1] = f32x2{r4[2], r4[3]};
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (col + r < n_out) og[r_in * n_out + col + r] = r4[r];
+          }
+        }
+      }
+    }
     // -------------------------------------------------------------- further output tiles (n_out > 16): from the X image
     if constexpr (NOTV == 4)
     for (int ot = NOT; ot < m.out_tiles; ++ot) {
@@ -750,12 +741,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 8: output layer
     if constexpr (kW0Late)
       if (grp + (int)gridDim.x < n_groups) fetch_w0();
-  }
-  if (kDeferOutput && group_no > 0) {
-    lane = lane0;
-    j = lane & 15;
-    g = lane >> 4;
-    reduce_output((int64_t)(blockIdx.x + (group_no - 1) * (int)gridDim.x) * kRows);
   }
   if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
 #undef RBL_NSTAMP
