@@ -2,8 +2,9 @@
 
 A sampler thread reads the SMU's gpu_metrics through amdsmi every ~10 ms (average / current socket power, current gfx clock
 of every XCD, hot-spot temperature) while the main thread keeps one workload's launches queued back to back for a few seconds:
-  idle | net forward, register-resident kernel (RBL_MLP_TILE=5) | the same with the software-pipelined kernel (6, if the
-  library still has it) | CFR step kernel alone (synthetic net) | the self-play mix of bench.py (net -> cfr per iteration)
+  idle | net forward, register-resident kernel (RBL_MLP_TILE=5; POWER_TRACE_TILES="5 3" adds the feature-split kernel -- the
+  tile-6 rows of profiles/r04_power_trace_tile5_vs_tile6.txt were taken at commit 6a4194a, before the software-pipelined
+  kernel left the product) | CFR step kernel alone (synthetic net) | the self-play mix of bench.py (net -> cfr per iteration)
 Prints one JSON object per phase: mean / p10 / p90 of power and clock over the phase's samples, us per launch (host clock
 over the whole phase), and for the net phases the cycles per 64-row group and CU that follow from the measured clock.
 usage: python scripts/power_trace.py [seconds per phase = 6] [rows = 589824]"""
@@ -126,7 +127,7 @@ def main():
                 "cycles_per_64row_group_at_measured_clock": o["us_per_launch"] * clk / groups_per_cu if clk else None,
                 "algorithmic_tflops": ROWS * 2 * (Q * 256 + 256 * 256 + 256 * H) / o["us_per_launch"] * 1e-6}
 
-    for tile in os.environ.get("POWER_TRACE_TILES", "5 6 5").split():
+    for tile in os.environ.get("POWER_TRACE_TILES", "5").split():
         os.environ["RBL_MLP_TILE"] = tile
         e.set_net_mlp(layers, ln, w_out, b_out)
         net_body()
