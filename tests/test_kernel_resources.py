@@ -1,0 +1,66 @@
+"""Compile-time resource guard for the two hot kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).  A scratch spill
+in the resident value-net kernel is a memory round trip inside its GEMM phases (it cost 9 k cycles per group
+once), and the one-wavefront CFR kernel needs <= 128 VGPRs for its four waves per SIMD -- both were lost and recovered more than
+once while the kernels were being changed, so the build checks them."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rebel_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _resources(src, extra=()):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I../../include", "-Wno-unused-result", *extra,
+           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull]
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    out, name = {}, None
+    for line in r.stdout.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        for key, pat in (("vgprs", r" VGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+            m = re.search(pat, line)
+            if m and name:
+                out[name][key] = int(m.group(1))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_resident_net_kernel_instantiations_that_are_launched_do_not_spill():
+    res = _resources("net_resident_kernel.hip")
+    seen = 0
+    for name, r in res.items():
+        m = re.search(r"mlp_resident_kernelILi(\d)ELb([01])ELi(\d)ELi(\d)E", name)
+        if not m:
+            continue
+        k0c, ln, notv, prod = (int(x) for x in m.groups())
+        seen += 1
+        # shapes no game reaches: one or two input chunks (n_in <= 64: at most 2 dice x 4 faces, 16 hands) with more than one
+        # output tile (> 16 hands)
+        unreachable = k0c <= 2 and notv >= 3
+        assert r["vgprs"] <= 256
+        if not unreachable:
+            assert r["scratch"] == 0, (name, r)
+    assert seen >= 48  # 4 input-chunk counts x (LayerNorm on / off) x 3 output variants, + the two half_inference modes
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_wave_cfr_kernel_keeps_four_waves_per_simd_for_the_one_die_games():
+    res = _resources("cfr_wave_kernel.hip", ("-ffp-contract=off",))
+    by_h = {}
+    for name, r in res.items():
+        m = re.search(r"cfr_wave_kernelILi(\d+)ELi(\d+)ELi(\d)ELi(\d)E", name)
+        if m:
+            by_h[(int(m.group(3)), int(m.group(4)))] = r
+    assert set(by_h) == {(1, 4), (1, 5), (1, 6), (2, 3)}
+    for game, r in by_h.items():
+        assert r["scratch"] == 0, (game, r)
+    # 1 die x 6 faces (the headline) and 1 die x 4 faces (config 2): 16 lanes per CU need <= 128 VGPRs
+    assert by_h[(1, 6)]["vgprs"] <= 128 and by_h[(1, 4)]["vgprs"] <= 128, by_h
