@@ -346,6 +346,11 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   }
   MlpPacked pk = pack_mlp(w.n_layers, n_in_pack, w.n_hidden, w.n_out, w.use_layer_norm, wv.data(), w.b, w.ln_w, w.ln_b,
                           w.w_out, w.b_out, tile);
+  // every refusal happens HERE, before the engine is touched: a rejected net leaves the previous one (blob, MlpDev, query
+  // layout, net mode) exactly as it was, so the caller can retry with rbl_engine_set_net_precision(e, 0)
+  if (net_precision_ != 0 && (pk.tile != 5 || !w.use_layer_norm))
+    throw std::runtime_error("set_net_mlp: the half_inference modes need the register-resident kernel and a LayerNorm net "
+                             "(hidden layers of 256; rbl_engine_set_net_precision(e, 0) for everything else)");
   // weight refresh (ModelLocker::updateModel, model_locker.h:69-79) happens between launches: no new forward can be
   // enqueued while we hold net_mutex_, and the ones already enqueued on either stream are drained first
   sync();
@@ -372,9 +377,6 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   mlp_.n_hidden = w.n_hidden;
   mlp_.n_out = w.n_out;
   mlp_.products = 3 - net_precision_;
-  if (net_precision_ != 0 && (pk.tile != 5 || !w.use_layer_norm))
-    throw std::runtime_error("set_net_mlp: the half_inference modes need the register-resident kernel and a LayerNorm net "
-                             "(one hidden layer of 256; rbl_engine_set_net_precision(e, 0) for everything else)");
   mlp_.use_ln = env_int("RBL_MLP_DEBUG", 0) == 1 ? 2 : w.use_layer_norm;
   mlp_.tile = pk.tile;
   if (env_int("RBL_NET_DBG", 0)) {

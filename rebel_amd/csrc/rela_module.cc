@@ -158,7 +158,12 @@ class ValuePrioritizedReplay {
     std::lock_guard<std::mutex> lk(m_);
     return safe_size_;
   }
-  int num_add() const { return num_add_; }
+  // 64-bit on purpose.  The reference's counter is an int (prioritized_replay.h:496) that its ~200 examples/s never
+  // fill; one MI355X adds ~94 k examples/s, so 2^31 is 6.3 h on one generating GPU and 54 min on seven -- and a negative
+  // num_add() stalls the unmodified trainer's train_gen_ratio gate for good (cfvpy/selfplay.py:391-404).  Python sees an
+  // int either way.
+  int64_t num_add() const { return num_add_.load(std::memory_order_relaxed); }
+  void set_num_add_for_test(int64_t v) { num_add_.store(v); }  // test hook: start the counter just under 2^31
 
   // ---- consumer side: sample (:263-296)
   std::tuple<ValueTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
@@ -360,7 +365,7 @@ class ValuePrioritizedReplay {
     sum_ += sum;
     lk.unlock();
     cv_tail_.notify_all();
-    num_add_ += (int)n;
+    num_add_.fetch_add(n, std::memory_order_relaxed);
     return true;
   }
 
@@ -518,7 +523,7 @@ class ValuePrioritizedReplay {
   torch::Tensor tq_, tv_;  // [ring][Q], [ring][V] f32, host memory or the producing GPU (ensure_layout)
   std::vector<float> weights_;
   std::vector<bool> evicted_;
-  std::atomic<int> num_add_{0};
+  std::atomic<int64_t> num_add_{0};
   std::mutex m_sampler_;
   std::vector<int> sampled_ids_;
   std::queue<std::future<Sampled>> futures_;
@@ -1085,6 +1090,7 @@ PYBIND11_MODULE(rela, m) {
       .def("extract", &ValuePrioritizedReplay::extract)
       .def("push", &ValuePrioritizedReplay::push, py::call_guard<py::gil_scoped_release>())
       .def("_storage_device", &ValuePrioritizedReplay::storage_device)  // not in the reference: where the rings live
+      .def("_set_num_add_for_test", &ValuePrioritizedReplay::set_num_add_for_test)  // not in the reference: test hook
       .def("update_priority", &ValuePrioritizedReplay::update_priority);
 
   py::class_<ThreadLoop, std::shared_ptr<ThreadLoop>>(m, "ThreadLoop");

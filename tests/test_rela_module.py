@@ -232,6 +232,25 @@ def test_blocks_larger_than_the_free_space_are_appended_in_chunks(ours):
     assert all((s % 3 == 0).all() for s in seen)  # every sampled row is a whole row of the source
 
 
+def test_num_add_does_not_wrap_at_2_to_31(ours):
+    """One MI355X adds ~94 k examples/s: an `int` counter (the reference's type, prioritized_replay.h:496) turns negative
+    after 6.3 h on one generating GPU, 54 min on seven, and the unmodified trainer's throttle
+    `num_add() * train_gen_ratio >= train_size * (epoch + 1)` (cfvpy/selfplay.py:391-404) then never opens again.  The
+    counter is 64-bit here: seeded just under 2^31 through the test hook, three more blocks keep it growing."""
+    r = ours.ValuePrioritizedReplay(capacity=64, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                    compressed_values=False)
+    start = 2 ** 31 - 10
+    r._set_num_add_for_test(start)
+    seen = [r.num_add()]
+    for _ in range(3):
+        r.push([torch.zeros(8, 3), torch.zeros(8, 2), torch.ones(8)])
+        seen.append(r.num_add())
+    assert seen == [start, start + 8, start + 16, start + 24] and seen[-1] > 2 ** 31
+    ratio, train_size, epoch = 4, 25600, 10 ** 5  # the gate of selfplay.py:391-404 with liars_sp.yaml's train_gen_ratio
+    assert r.num_add() * ratio >= train_size * (epoch + 1)
+    assert r.size() == 24
+
+
 def test_context_plans_one_engine_per_model_locker_device(ours, monkeypatch):
     """The in-process multi-GPU topology (cfvpy/selfplay.py:187-252: one ModelLocker per generating GPU, threads_per_gpu
     create_cfr_thread calls each, seeds rank*1000+i): Context.start() builds one worker = one engine + one driver thread
