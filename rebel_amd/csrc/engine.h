@@ -160,6 +160,11 @@ class Engine {
   struct Timed;
   void time_begin(int kind, hipStream_t st);
   bool time_end(int kind, hipStream_t st);  // false: the sample was dropped (see launch_timing.h)
+  void time_abort();                        // forget a sample that time_begin opened and time_end never closed
+  struct TimingAbortGuard {                 // scope guard of launch() / run_net(): disarms the slot, drops an open sample
+    Engine* e;
+    ~TimingAbortGuard() { e->time_abort(); }
+  };
 
   int device_;
   Rules g_;
@@ -262,6 +267,7 @@ class Engine {
   // reports) while the launch is ONE kernel of a launcher that supports it; otherwise bracket with recorded events
   bool ext_timing_[2] = {true, true};
   bool ext_armed_ = false;
+  bool sample_open_ = false;  // between time_begin and time_end
   std::vector<Pending> pending_;
   size_t ev_used_ = 0;
   rbl_kernel_stats stats_{};

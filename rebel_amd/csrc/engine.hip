@@ -483,6 +483,18 @@ void Engine::time_begin(int kind, hipStream_t st) {
   }
   pending_.push_back(Pending{kind, ev_used_, ev_used_ + 1});
   ev_used_ += 2;
+  sample_open_ = true;
+}
+
+// Unwinding between time_begin and time_end (a failed launch: RBL_HIP_CHECK, launch_cfr_flat's LDS attribute error): the open
+// sample's event pair was never (both) recorded, so it must not reach stats()' hipEventElapsedTime.  The two events stay
+// consumed until the next stats() -- they may already be bound to a dispatch -- only the sample is forgotten.
+void Engine::time_abort() {
+  tl_launch_timing = LaunchTimingSlot{};
+  if (!sample_open_) return;
+  sample_open_ = false;
+  ext_armed_ = false;
+  if (!pending_.empty()) pending_.pop_back();
 }
 
 bool Engine::time_end(int kind, hipStream_t st) {
@@ -491,15 +503,17 @@ bool Engine::time_end(int kind, hipStream_t st) {
     const int used = tl_launch_timing.used;
     tl_launch_timing = LaunchTimingSlot{};
     ext_armed_ = false;
+    sample_open_ = false;
     if (used == 1) return true;
     // none or several kernels took the slot (a launcher without support, segmented launches): this sample has no valid
-    // event pair; from now on this kind is bracketed with recorded events
+    // event pair; from now on this kind is bracketed with recorded events.  The pair is NOT handed out again before the next
+    // stats(): it may be bound to several dispatches that are still in flight.
     ext_timing_[kind] = false;
-    ev_used_ -= 2;
     pending_.pop_back();
     return false;
   }
   RBL_HIP_CHECK(hipEventRecord(ev_pool_[pending_.back().e1], st));
+  sample_open_ = false;
   return true;
 }
 
@@ -810,7 +824,7 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.optimistic = p_.optimistic ? 1 : 0;
   a.br_out = d_br_.p;
   a.dbg = cfr_dbg_ ? d_dbg_.p : nullptr;
-  LaunchTimingDisarm disarm_on_exit;
+  TimingAbortGuard abort_open_sample_on_unwind{this};
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int l0 = part_lane_[part], cnt = part_lane_[part + 1] - l0;
@@ -877,7 +891,7 @@ void Engine::run_net() {
     return;
   }
   const int Q = g_.query_size(), H = g_.H;
-  LaunchTimingDisarm disarm_on_exit;
+  TimingAbortGuard abort_open_sample_on_unwind{this};
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
     const int64_t r0 = part_row_[part], nr = part_row_[part + 1] - r0;

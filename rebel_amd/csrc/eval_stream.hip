@@ -1289,6 +1289,13 @@ struct StreamSolver {
     if (!d_samp.p) sampled_reset();
     const double t0 = now_s();
     const int H = g.H, D = e.params().max_depth;
+    // ONE subgame_params for every subgame of the repeat, as in the reference (recursive_solving.cc:301-327): the forest below
+    // the root discounts with the ENGINE's parameters, never with this stream solver's own `p` (they may have been created
+    // with different ones); what the forest's kernels do not implement is refused instead of silently diverging
+    const rbl_params& ep = e.params();
+    if (!ep.use_cfr) throw std::runtime_error("sampled_add(root_only): the forest solve is CFR only (engine params use_cfr = 0)");
+    // (`optimistic` is read by fictitious play only, subgame_solving.cc:452: CFR ignores it, here as there; dcfr_gamma discounts
+    //  sum_strategies, which a sampling strategy never reads)
     std::vector<int32_t> leaf_act;
     const int root_act = draw_act_iterations_root_only(ft, g, D, e.params().num_iters, seed, &leaf_act);
     // the root subgame: recursive_fill's first level with the root's own stop iteration; it scatters the sampling strategy
@@ -1341,11 +1348,11 @@ struct StreamSolver {
         const int t = it % 2;
         const double sdisc = steps[t] + 1;
         double pos = 1, neg = 1;
-        if (p.linear_update) {
+        if (ep.linear_update) {
           pos = neg = sdisc / (sdisc + 1);
-        } else if (p.dcfr) {
-          pos = p.dcfr_alpha >= 5 ? 1 : std::pow(sdisc, p.dcfr_alpha) / (std::pow(sdisc, p.dcfr_alpha) + 1.);
-          neg = p.dcfr_beta <= -5 ? 0 : std::pow(sdisc, p.dcfr_beta) / (std::pow(sdisc, p.dcfr_beta) + 1.);
+        } else if (ep.dcfr) {
+          pos = ep.dcfr_alpha >= 5 ? 1 : std::pow(sdisc, ep.dcfr_alpha) / (std::pow(sdisc, ep.dcfr_alpha) + 1.);
+          neg = ep.dcfr_beta <= -5 ? 0 : std::pow(sdisc, ep.dcfr_beta) / (std::pow(sdisc, ep.dcfr_beta) + 1.);
         }
         // opponent reach from the roots' beliefs, top-down under sigma
         hipLaunchKernelGGL(forest_root_reach_kernel, dim3((unsigned)((count * H + 255) / 256)), dim3(256), 0, st, f_nodes.p, bel.p,

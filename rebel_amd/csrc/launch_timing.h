@@ -18,11 +18,7 @@ struct LaunchTimingSlot {
 };
 extern thread_local LaunchTimingSlot tl_launch_timing;
 
-// Scope guard of the code that arms the slot: whatever happens between arming and the launch (an exception from a failed
-// launch, an early return), the slot does not stay armed with events of an engine that may be gone by the next launch.
-struct LaunchTimingDisarm {
-  ~LaunchTimingDisarm() { tl_launch_timing = LaunchTimingSlot{}; }
-};
+// (The engine's TimingAbortGuard disarms the slot when the code between arming and the launch unwinds: engine.h.)
 
 }  // namespace rbl
 

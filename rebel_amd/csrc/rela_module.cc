@@ -658,12 +658,25 @@ int apply_mlp(rbl_engine* e, const MlpHost& mlp) {
   int mode = 0;
   if (mlp.half) {
     const char* env = std::getenv("REBEL_AMD_HALF_INFERENCE");
-    mode = env ? std::atoi(env) : 2;
-    if (mode < 0 || mode > 2) mode = 2;
-    if (!mlp.use_ln || mlp.n_layers != 2 || mlp.n_hidden != 256) mode = 0;
+    mode = 2;
+    if (env && *env) {
+      char* end = nullptr;
+      const long v = std::strtol(env, &end, 10);
+      // anything that is not exactly 0, 1 or 2 selects the parity arithmetic (mode 0), never a narrower one by accident
+      mode = (end && *end == 0 && v >= 0 && v <= 2) ? (int)v : 0;
+    }
   }
+  // Both calls happen under the caller's lock (ModelLocker::m_; an engine belongs to one locker), so two updateModel calls
+  // cannot interleave their modes.  A half module whose shape the register-resident kernel does not take (no LayerNorm, more
+  // hidden layers than it keeps resident, RBL_MLP_TILE=3) is refused by set_net_mlp BEFORE the engine is touched: retry in the
+  // f32-parity arithmetic, which every supported shape has.
   if (int st = rbl_engine_set_net_precision(e, mode)) return st;
-  return rbl_engine_set_net_mlp(e, &c);
+  int st = rbl_engine_set_net_mlp(e, &c);
+  if (st != 0 && mode != 0) {
+    if (int st0 = rbl_engine_set_net_precision(e, 0)) return st0;
+    st = rbl_engine_set_net_mlp(e, &c);
+  }
+  return st;
 }
 
 class ModelLocker {

@@ -214,6 +214,33 @@ def test_half_inference_modes_are_refused_where_they_do_not_exist():
     e.set_net_mlp(layers, None, rng.uniform(-1, 1, (e.H, 256)).astype(np.float32), np.zeros(e.H, np.float32))
 
 
+def test_a_refused_net_leaves_the_previous_one_intact():
+    """set_net_mlp used to reject an unsupported precision / net combination only after it had replaced
+    the weight blob, reset the kernel descriptor and switched the query layout -- a live engine was left wedged ('unknown
+    kernel variant' on every later forward).  Every refusal now happens before the engine is touched: the forward of the
+    net that was there still gives the same answers bit for bit, and a retry in mode 0 works."""
+    from rebel_amd import capi
+
+    weights, q, ref64, _ = _half_case(1, 6, 500, seed=11)
+    e = _engine(1, 6)
+    e.set_net_mlp(*weights)
+    before = e.net_forward(q)
+    assert np.abs(before - ref64).max() <= ATOL
+    rng = np.random.default_rng(1)
+    no_ln = [(rng.uniform(-1, 1, (256, e.Q)).astype(np.float32), np.zeros(256, np.float32)),
+             (rng.uniform(-1, 1, (256, 256)).astype(np.float32), np.zeros(256, np.float32))]
+    w_out, b_out = rng.uniform(-1, 1, (e.H, 256)).astype(np.float32), np.zeros(e.H, np.float32)
+    e.set_net_precision(2)
+    with pytest.raises(capi.RebelError, match="half_inference"):
+        e.set_net_mlp(no_ln, None, w_out, b_out)
+    assert np.array_equal(e.net_forward(q), before)  # same blob, same descriptor, same layout
+    assert e.stats()["net_products"] == 3
+    e.set_net_precision(0)
+    e.set_net_mlp(no_ln, None, w_out, b_out)  # the retry the message suggests
+    y = e.net_forward(q)
+    assert np.abs(y - _np_net(q, no_ln, None, w_out, b_out)).max() <= ATOL * max(1.0, np.abs(y).max())
+
+
 def test_half_inference_edge_batches():
     for rows in (1, 63, 64 * 256 + 1):
         for mode in (1, 2):
