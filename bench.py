@@ -27,10 +27,16 @@ The JSON line also carries
   traffic       HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
                 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, which cannot be taken inside a timed run; FETCH x2
                 per the gfx950 note of the guide)
-  configs       the other BASELINE.json configurations on the same engine (N = 1 only): 1dx4f @1024 x 4 096 lanes, 2dx3f
-                @1024 x 16 384 lanes, 2dx6f @2048 x 2 048 lanes -- value, ms_per_step, both kernels' roofline fractions
-                and the reference path's rate on this box's host cores
+  configs       the other BASELINE.json configurations on the same engine (N = 1 only): configs[0] 1dx4f @128 (the reference's
+                plumbing case: its CPU path with ONE generator thread), 1dx4f @1024 x 4 096 lanes, 2dx3f @1024 x 16 384 lanes,
+                2dx6f @2048 x 2 048 lanes -- value, ms_per_step, both kernels' roofline fractions and the reference path's
+                rate on this box's host cores
   per_gpu       (N > 1) every rank's own rate and roofline fractions, and the ranks the RCCL process group saw
+  rela_boundary the SAME metric measured the reference's way, through the drop-in boundary (cfvpy/selfplay.py:187-252, 285-293;
+                gen_benchmark.cc:146-153): scripted Net2 in a rela.ModelLocker, rela.ValuePrioritizedReplay(capacity 2 000 000),
+                1 024 x create_cfr_thread (x16 lanes each), Context.start(); rate = delta replay.num_add() / 2 x subgame_iters /
+                wall-clock between epoch boundaries, WHILE a consumer thread calls replay.sample(512, "cuda:0") in a loop and
+                locker.update_model(net) every 2 s
   cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so) timed on this box's host cores for >= 30 s per
                 generator-thread count in {16, 32, 60 (README), os.cpu_count()} -- a reported baseline, not a target.
 """
@@ -50,12 +56,18 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense f
 MFMA_F32_PEAK_TFLOPS = 157.3   # same guide: f32-input MFMA peak (= f32 vector peak), quoted for context
 HBM_PEAK_GBPS = 8000.0         # same guide: HBM3E spec peak
 
-# BASELINE.json configs[1], [3], [4] as single-GPU legs of the `configs` block (configs[2] is the headline, configs[0] the
-# reference's own CPU plumbing case): (index, dice, faces, subgame_iters, lanes)
-OTHER_CONFIGS = [(1, 1, 4, 1024, 4096), (3, 2, 3, 1024, 16384), (4, 2, 6, 2048, 2048)]
+# BASELINE.json configs[0], [1], [3], [4] as single-GPU legs of the `configs` block (configs[2] is the headline):
+# (index, dice, faces, subgame_iters, lanes).  configs[0] is the reference's own plumbing case -- 1 die x 4 faces, 128
+# iterations, cpu_gen_threads = 1 on its CPU path: its `cpu_reference` is timed with ONE
+# generator thread; the engine leg beside it runs the same game and iteration count on 4 096 lanes.
+OTHER_CONFIGS = [(0, 1, 4, 128, 4096), (1, 1, 4, 1024, 4096), (3, 2, 3, 1024, 16384), (4, 2, 6, 2048, 2048)]
 
 
 def cpu_baseline(dice, faces, iters, seconds, threads=0):
+    """The UNMODIFIED reference path (oracle/_ref) timed on this box's host cores -> dict, or None + the reason when the
+    compiled reference is not there.  Nothing is substituted for it: a line either carries the reference's own rate or
+    `cpu_baseline: null` with `cpu_baseline_error` (round 4 fell back to the port oracle with a synthetic net, which
+    silently changed what the key meant)."""
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--dice", str(dice), "--faces", str(faces),
            "--iters", str(iters), "--seconds", str(seconds), "--threads", str(threads)]
     try:
@@ -64,20 +76,9 @@ def cpu_baseline(dice, faces, iters, seconds, threads=0):
         out = json.loads(line)
         if "error" in out:
             raise RuntimeError(out["error"])
-        return {k: out[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}
-    except Exception as ex:  # the reference build is absent: fall back to timing the port oracle (zero net), 1 thread
-        from oracle import orc
-
-        port = orc.Oracle("port")
-        p = orc.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
-        t0, games, subgames = time.time(), 0, 0.0
-        while time.time() - t0 < min(seconds, 20):
-            subgames += len(port.rl_run(dice, faces, p, games, 1, net=orc.NET_SYNTHETIC)) / 2
-            games += 1
-        return {"value": subgames * iters / (time.time() - t0), "unit": "subgame-CFR-iterations/s", "cores": 1,
-                "host_cores": os.cpu_count(), "kind": "port",
-                "sample": f"reference build unavailable ({ex}); port oracle, 1 thread, {games} games, elementwise "
-                          f"synthetic net instead of Net2 (so this OVERSTATES the CPU path)"}
+        return {k: out[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample")}, None
+    except Exception as ex:
+        return None, f"reference CPU path not measured: {ex}"
 
 
 class PowerSampler:
@@ -129,11 +130,113 @@ class PowerSampler:
                 "power_cap_w": self.cap_w, "samples": len(s), "source": "amdsmi gpu_metrics at ~10 ms over the timed region"}
 
 
-def spawn_ranks(n_gpus):
+def rela_boundary_leg(dice, faces, iters, lanes, device_index, epochs, consumer):
+    """The metric the reference's way, through the drop-in boundary: exactly cfvpy/selfplay.py:187-252 (initialize_datagen) and
+    :285-293 / gen_benchmark.cc:146-153 (rate = replay.num_add() / wall-clock), with a trainer-shaped consumer beside the
+    generators -- replay.sample(512, device) in a loop (selfplay.py:411 per train iteration) and ModelLocker.update_model(net)
+    every 2 s (selfplay.py: network_sync_epochs).  num_add() is polled at ~0.3 ms: it moves once per epoch (2 x lanes examples
+    appended as one block), so the time stamps of its changes ARE the epoch boundaries and the rate is exact over whole epochs --
+    the fixed 8 s window of rounds 3-4 (scripts/probe_rela_throughput.py) cut an epoch in two at either end (+-4 %)."""
+    import threading
+
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    per = 16  # lanes per create_cfr_thread call: 1 024 calls (selfplay.py:250 seeds rank*1000+i; INTEGRATION.md) x 16
+    threads = max(1, lanes // per)
+    dev = f"cuda:{device_index}"
+    prev = os.environ.get("REBEL_AMD_LANES_PER_THREAD")
+    os.environ["REBEL_AMD_LANES_PER_THREAD"] = str(per)
+    ctx = None
+    try:
+        torch.manual_seed(0)
+        net = Net2(num_faces=faces, num_dice=dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+        ref_model = torch.jit.script(Net2(num_faces=faces, num_dice=dice, n_hidden=256, use_layer_norm=True, n_layers=2).to(dev)).eval()
+        ref_model.load_state_dict(net.state_dict())
+        locker = rela.ModelLocker([ref_model], dev)
+        # liars_sp.yaml's replay block (capacity 2 000 000, alpha 1, beta 1, prefetch 8, use_priority false)
+        replay = rela.ValuePrioritizedReplay(capacity=2000000, seed=10001, alpha=1.0, beta=1.0, prefetch=8, use_priority=False,
+                                             compressed_values=False)
+        cfg = rela.RecursiveSolvingParams()
+        cfg.num_dice, cfg.num_faces, cfg.random_action_prob, cfg.sample_leaf = dice, faces, 0.25, True
+        sp = cfg.subgame_params
+        sp.num_iters, sp.max_depth, sp.linear_update, sp.use_cfr = iters, 2, True, True
+        ctx = rela.Context()
+        for i in range(threads):
+            ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, i))
+        stop = threading.Event()
+        seen = {"samples": 0, "updates": 0, "error": None}
+
+        def consume():
+            last = time.perf_counter()
+            try:
+                while not stop.is_set():
+                    if replay.size() < 1024:  # burn-in, selfplay.py:314-327
+                        time.sleep(0.005)
+                        continue
+                    batch, _ = replay.sample(512, dev)
+                    assert batch.query.shape[0] == 512
+                    seen["samples"] += 1
+                    if time.perf_counter() - last >= 2.0:
+                        locker.update_model(net)
+                        seen["updates"] += 1
+                        last = time.perf_counter()
+            except Exception as ex:  # reported in the line, never swallowed
+                seen["error"] = repr(ex)
+
+        th = threading.Thread(target=consume, daemon=True)
+        ctx.start()
+        if consumer:
+            th.start()
+        lanes_run = threads * per
+        stamps, last_n, t_begin = [], 0, time.perf_counter()
+        skip = 2  # the first epochs carry engine creation and the cold start
+        while len(stamps) < skip + epochs + 1:
+            n = replay.num_add()
+            if n != last_n:
+                stamps.append((time.perf_counter(), n))
+                last_n = n
+            if time.perf_counter() - t_begin > 600:
+                raise RuntimeError(f"rela leg: only {len(stamps)} epochs in 600 s")
+            if ctx.terminated():
+                raise RuntimeError("rela leg: the generators stopped")
+            time.sleep(0.0003)
+        t_samples0 = seen["samples"]
+        stop.set()
+        if consumer:
+            th.join(30)
+        (t0, n0), (t1, n1) = stamps[skip], stamps[-1]
+        per_epoch = sorted((b[0] - a[0]) * 1e3 for a, b in zip(stamps[skip:-1], stamps[skip + 1:]))
+        out = {"value": (n1 - n0) / 2 * iters / (t1 - t0), "unit": "subgame-CFR-iterations/s", "examples_per_s": (n1 - n0) / (t1 - t0),
+               "epochs": len(stamps) - 1 - skip, "ms_per_epoch_median": per_epoch[len(per_epoch) // 2],
+               "ms_per_epoch_max": per_epoch[-1], "examples_per_epoch": (n1 - n0) // (len(stamps) - 1 - skip),
+               "lanes": lanes_run, "create_cfr_thread_calls": threads, "lanes_per_thread": per,
+               "replay": {"capacity": 2000000, "use_priority": False, "prefetch": 8, "storage": replay._storage_device()},
+               "consumer": ({"sample_calls_per_s": t_samples0 / max(1e-9, stamps[-1][0] - stamps[0][0]), "batch": 512,
+                             "update_model_calls": seen["updates"], "error": seen["error"]} if consumer else None)}
+        return out
+    finally:
+        if ctx is not None:
+            ctx.terminate()
+            t_end = time.time()
+            while not ctx.terminated() and time.time() - t_end < 60:
+                time.sleep(0.01)
+            del ctx
+        if prev is None:
+            os.environ.pop("REBEL_AMD_LANES_PER_THREAD", None)
+        else:
+            os.environ["REBEL_AMD_LANES_PER_THREAD"] = prev
+
+
+def spawn_ranks(n_gpus, share_gpu=False):
     """`--gpus N` without a rank environment: start the N ranks ourselves, one process per GPU (torch.distributed.run)."""
     import torch
 
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if share_gpu and have >= 1:
+        have = n_gpus  # test-only: every rank on GPU 0 (see --share-gpu)
     if have < n_gpus:
         sys.stderr.write(f"bench.py: --gpus {n_gpus} was asked for but {have} GPU(s) are visible on this box; refusing to "
                          f"measure fewer GPUs than the line would claim (n_gpus)\n")
@@ -208,12 +311,19 @@ def main():
                     help="skip the comparison legs and the `configs` block (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block only")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY (a box with one GPU): every rank runs its engine on GPU 0 and the bookkeeping goes over gloo "
+                         "(RCCL refuses two ranks on one device).  The line says so; it is never a scaling number")
+    ap.add_argument("--dump-examples", default=None,
+                    help="TEST ONLY: directory; every rank saves the timed epochs' training examples as rank<r>.npz")
+    ap.add_argument("--rela-epochs", type=int, default=int(os.environ.get("BENCH_RELA_EPOCHS", 12)),
+                    help="timed epochs of the rela_boundary leg (0 = skip the leg)")
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
-        sys.exit(spawn_ranks(a.gpus))
+        sys.exit(spawn_ranks(a.gpus, a.share_gpu))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -223,12 +333,14 @@ def main():
                          f"rank environment, then bench.py starts the ranks itself)\n")
         sys.exit(2)
 
-    import numpy as np  # noqa: F401
+    import numpy as np
     import torch  # first: librebel_hip.so then binds to the HIP runtime torch already loaded (same SONAME)
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: rebel_amd has no CPU fallback")
+    if a.share_gpu:
+        local_rank = 0  # every rank's engine on GPU 0
     if torch.cuda.device_count() <= local_rank:
         raise RuntimeError(f"bench.py: rank {rank} wants GPU {local_rank} but {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
@@ -236,7 +348,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from rebel_amd import capi
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
@@ -256,7 +371,7 @@ def main():
 
     power = {}
 
-    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0, sample_power=False):
+    def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0, sample_power=False, dump=None):
         """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
         dice, faces, iters = game
         params = capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
@@ -276,10 +391,13 @@ def main():
         if sync_ranks:
             barrier()
         t0 = time.perf_counter()
+        kept = []
         for _ in range(steps):
             n, lanes_, q, v = sp.advance(collect=True)  # examples land in host arrays = the replay push hand-off
             units += n
             n_ex += len(lanes_)
+            if dump:
+                kept.append((q, v))
         eng.sync()
         if sync_ranks:
             barrier()
@@ -288,6 +406,10 @@ def main():
             power["headline"] = sampler.summary(t0, t0 + dt)
         st = eng.stats(reset=True)
         eng.timing(0)
+        if dump:
+            os.makedirs(dump, exist_ok=True)
+            np.savez(os.path.join(dump, f"rank{rank}.npz"), q=np.stack([k[0] for k in kept]), v=np.stack([k[1] for k in kept]),
+                     seeds=np.asarray(lane_seeds(rank, lanes)))
         games = sp.games_finished() - games0
         on_device = sp.on_device()
         sp.close()
@@ -302,7 +424,8 @@ def main():
         return net_t, cfr_t, net_tf, cfr_gb
 
     headline = (a.dice, a.faces, a.iters)
-    dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True, sample_power=rank == 0)
+    dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True, sample_power=rank == 0,
+                                                                  dump=a.dump_examples)
     net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
 
     dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
@@ -332,6 +455,16 @@ def main():
         # accumulation, f32 LayerNorm / GELU -- at least as accurate as the half torch module, tests/test_net_parity.py)
         hdt, hunits, _, _, hst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False, precision=2)
         half_leg = (hdt, hunits, hst)
+
+    rela_leg = None
+    if world == 1 and rank == 0 and not a.no_extra_legs and a.rela_epochs > 0:
+        try:
+            rela_leg = rela_boundary_leg(a.dice, a.faces, a.iters, a.lanes, local_rank, a.rela_epochs, consumer=True)
+            rela_leg["without_consumer"] = {k: v for k, v in rela_boundary_leg(a.dice, a.faces, a.iters, a.lanes, local_rank,
+                                                                               max(4, a.rela_epochs // 2), consumer=False).items()
+                                            if k in ("value", "unit", "epochs", "ms_per_epoch_median")}
+        except Exception as ex:  # the leg must not cost the headline its line; the failure is in the line instead
+            rela_leg = {"value": None, "error": repr(ex)}
 
     def roofline_blocks(game, st, streams_):
         """The `roofline` / `roofline_cfr` objects of one leg from its kernel stats."""
@@ -429,6 +562,8 @@ def main():
             # the dominant kernel is socket-power-bound (84 % of the step at ~1.39 kW of a 1.4 kW cap): see DESIGN.md 3.2d
             out["power"] = power["headline"]
         if per_rank:
+            if a.share_gpu:
+                out["share_gpu"] = "TEST MODE: every rank ran on GPU 0 (gloo bookkeeping); not a scaling measurement"
             out["per_gpu"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
                               "ranks": [{"rank": int(r[0]), "gpu": int(r[1]), "value": r[2], "seconds": r[3], "net_frac_mfma": r[4],
                                          "cfr_frac_hbm": r[5], "cfr_gbps": r[6], "net_launch_us": r[7], "cfr_launch_us": r[8]}
@@ -447,15 +582,27 @@ def main():
             out["lanes_4096"] = lanes4096
         if two_streams:
             out["two_streams"] = two_streams
+        if rela_leg is not None:
+            out["rela_boundary"] = rela_leg
+            if rela_leg.get("value"):
+                rela_leg["ratio_to_value"] = rela_leg["value"] / out["value"]
+                nc = rela_leg.get("without_consumer")
+                if nc and nc.get("value"):
+                    nc["ratio_to_value"] = nc["value"] / out["value"]
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
-            if out["cpu_baseline"].get("value"):
+            out["cpu_baseline"], err = cpu_baseline(a.dice, a.faces, a.iters, a.cpu_seconds)
+            if err:
+                out["cpu_baseline_error"] = err
+            elif out["cpu_baseline"].get("value"):
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-            best_threads = out["cpu_baseline"].get("cores", 16) if out["cpu_baseline"].get("kind") == "reference" else 16
+            best_threads = out["cpu_baseline"].get("cores", 16) if out["cpu_baseline"] else 16
             for c in configs:  # the reference path on the same configuration, at the headline's best generator-thread count
-                d_, f_, it_ = next((d, f, it) for i, d, f, it, _ in OTHER_CONFIGS if i == c["baseline_config"])
-                c["cpu_reference"] = cpu_baseline(d_, f_, it_, a.config_cpu_seconds, threads=best_threads)
-                if c["cpu_reference"].get("value"):
+                i_, d_, f_, it_ = next((i, d, f, it) for i, d, f, it, _ in OTHER_CONFIGS if i == c["baseline_config"])
+                # configs[0] is quoted at cpu_gen_threads = 1 (BASELINE.json): one generator thread there
+                c["cpu_reference"], err = cpu_baseline(d_, f_, it_, a.config_cpu_seconds, threads=1 if i_ == 0 else best_threads)
+                if err:
+                    c["cpu_reference_error"] = err
+                elif c["cpu_reference"].get("value"):
                     c["speedup_vs_cpu_reference"] = c["value"] / c["cpu_reference"]["value"]
         if configs:
             out["configs"] = configs

