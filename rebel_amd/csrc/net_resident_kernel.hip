@@ -30,8 +30,10 @@
 // instructions, against 37 in the tile-3 kernel.  Measured (MI355X, 270k rows): 18.8 k cycles per 64-row group and CU
 // (tile 3: 24.7 k), ~145 us per launch alone; PMC: MFMA busy 33 % + VALU busy 45 % of the time, never together.
 //
-// Supported shape: n_layers == 2 (one hidden layer, the reference's configuration liars_sp.yaml:28-33), n_hidden == 256,
-// n_in <= 128, n_out <= 64.  Anything else stays on the tile-3 kernel.
+// Supported shapes: n_hidden == 256 and either n_layers == 2 (one hidden layer, the reference's configuration
+// liars_sp.yaml:28-33; n_in <= 128, n_out <= 64) or n_layers == 3 (Net2's class default, cfvpy/models.py:73; n_in <= 64,
+// n_out <= 16: every one-die game and 2 dice x 3 faces -- template parameter NH below).  Anything else stays on the tile-3
+// kernel.
 #include <stdexcept>
 #include <type_traits>
 
@@ -243,7 +245,14 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
 // through the X image.  (The X-image loop is compiled into variant 4 only: next to the prefetched layer-0 weights of the next
 // group its fragments pushed the K0C = 4 kernel 40 VGPRs over budget, and hipcc spilled RESIDENT hidden weights for it --
 // reloaded from scratch, with a full vmcnt wait, inside the hidden GEMM of every group.)
-template <int K0C, bool LN, int NOTV, int PROD>
+// NH: hidden 256 x 256 layers (n_layers - 1).  1 = the reference's configuration (liars_sp.yaml:28-33); 2 = the class default
+// of Net2 (cfvpy/models.py:73, n_layers = 3).  Two hidden layers are 512 KB of hi + lo fragments -- the whole register file of
+// a CU -- so each keeps HALF of its k-steps resident (2 x 64 VGPRs) and streams the other four from L2 per group through
+// gemm_hidden: two requested before the preceding epilogue (its VALU work covers the round trip), two inside the GEMM behind
+// the four resident k-steps.  (First built as "first layer resident, second through a ring of 2-3 k-step slots": 256 KB per CU
+// had to arrive inside ONE 4 k-cycle GEMM phase -- exactly the 64 B/clk of the L2 -> CU path -- and that GEMM took 9 k cycles
+// whatever the ring depth; split over both GEMMs and both epilogues the same bytes have 4x the time.)
+template <int K0C, bool LN, int NOTV, int PROD, int NH>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups,
                                                                     const long long* __restrict__ range) {
@@ -257,7 +266,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     rows = r1 - r0;
     n_groups = (int)((rows + kRows - 1) / kRows);
   }
-  constexpr int kParamFloats = 2 * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
+  constexpr int kParamFloats = (NH + 1) * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
+  constexpr int kOutBias = (NH + 1) * 3 * 256;
   constexpr int kWoF4 = kKS * 2 * 64;             // one output tile's weight fragments (16 KB)
   // kEarlyStage: the next group's queries are turned into B fragments in a region of their own (Xq) while this group's
   // hidden GEMM drains, so a group starts with its layer-0 GEMM instead of a staging phase and a barrier (round 4: ~830 of
@@ -311,11 +321,27 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #ifndef RBL_KEARLY
 #define RBL_KEARLY 2
 #endif
-  constexpr int kTail = K0C == 1 ? 0 : (K0C == 2 ? 1 : (K0C == 3 ? RBL_KTAIL3 : RBL_KTAIL4)), kRes = kKS - kTail,
-                kEarly = kTail < RBL_KEARLY ? kTail : RBL_KEARLY, kE1 = kEarly > 0 ? kEarly : 1;
+#ifndef RBL_NH2_TAIL
+#define RBL_NH2_TAIL 5
+#endif
+#ifndef RBL_NH2_TAIL2
+#define RBL_NH2_TAIL2 6
+#endif
+#ifndef RBL_NH2_EARLY
+#define RBL_NH2_EARLY 3
+#endif
+#ifndef RBL_NH2_PF
+#define RBL_NH2_PF 2
+#endif
+  // with two hidden layers each keeps kKS - kTail k-steps resident (see NH above)
+  constexpr int kTail1 = K0C == 1 ? 0 : (K0C == 2 ? 1 : (K0C == 3 ? RBL_KTAIL3 : RBL_KTAIL4));
+  constexpr int kTailNH2 = K0C == 1 ? RBL_NH2_TAIL : RBL_NH2_TAIL2;
+  constexpr int kTail = NH == 2 && kTail1 < kTailNH2 ? kTailNH2 : kTail1, kRes = kKS - kTail,
+                kEarlyMax = NH == 2 ? RBL_NH2_EARLY : RBL_KEARLY, kEarly = kTail < kEarlyMax ? kTail : kEarlyMax,
+                kE1 = kEarly > 0 ? kEarly : 1;
   // B fragments requested this many steps ahead of their MFMAs; 1 with three or four input chunks (a third ring slot = 8
   // more VGPRs made hipcc spill 36-bytes' worth of resident weights at K0C = 3)
-  constexpr int kPF = K0C >= 3 ? 1 : 2;
+  constexpr int kPF = K0C >= 3 ? 1 : (NH == 2 ? RBL_NH2_PF : 2);
 #ifndef RBL_W0_LATE_MIN
 #define RBL_W0_LATE_MIN 3
 #endif
@@ -331,10 +357,22 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         if (PROD >= 2) w1l[ks][ot].v = w1[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
       }
   }
+  constexpr int kRes2 = NH == 2 ? kRes : 1;
+  Frag w2h[kRes2][kOTW], w2l[kRes2][kOTW];
+  const f32x4* w2 = w1 + (size_t)kWaves * kKS * kOTW * 2 * 64;  // [layer][wave][k-step][tile][part]: one layer further
+  if constexpr (NH == 2) {
+#pragma unroll
+    for (int ks = 0; ks < kRes; ++ks)
+#pragma unroll
+      for (int ot = 0; ot < kOTW; ++ot) {
+        w2h[ks][ot].v = w2[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+        if (PROD >= 2) w2l[ks][ot].v = w2[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+      }
+  }
   // per-feature parameters and the first output tile's weights: LDS copies (read every group, by every thread)
   for (int i = tid; i < 256; i += kWaves * 64) {
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < NH + 1; ++l) {
       // the bias rides in the accumulators' initial value, in the GEMM's own scale (weights are packed times a power of two
       // S = 1 / inv_scale; the scaling back happens once per row, inside the LayerNorm factor)
       prm[(l * 3 + 0) * 256 + i] = K0C <= 2 ? m.bias[l * 256 + i] / m.inv_scale[l] : m.bias[l * 256 + i];
@@ -342,7 +380,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       prm[(l * 3 + 2) * 256 + i] = m.ln_b[l * 256 + i];
     }
   }
-  if (tid < 64) prm[2 * 3 * 256 + tid] = tid < m.n_out ? m.b_out[tid] : 0.f;
+  if (tid < 64) prm[kOutBias + tid] = tid < m.n_out ? m.b_out[tid] : 0.f;
 
   // Query rows of a group, fetched straight in B-fragment order: thread (row tile = wave >> 1, half = wave & 1, j, g)
   // reads k = 32 ks + 8 g + 4 half + {0..3} of row 16 rt + j (a row is 4 n_in contiguous bytes; the 8 threads of a
@@ -562,8 +600,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // registers are free again (after the last epilogue of the previous group), so the round trip is off the critical path.
   Frag th[K0C][kOTW], tl[K0C][kOTW];
   auto fetch_w0 = [&]() {
-    const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64;
-    asm volatile("" : "+s"(w0));  // a fresh load every group (the values are loop invariant; hoisting = residency)
+    // a fresh load every group (the values are loop invariant; hoisting = residency).  The opaque value is an OFFSET, not the
+    // pointer: a pointer that went through an asm operand comes back in the generic address space, and hipcc then emits
+    // FLAT loads -- which count on lgkmcnt as well as vmcnt, so every LDS wait and LDS barrier that followed (the output
+    // reduction, the next GEMM's fragment ring) also waited for these L2 round trips (rounds 2-4 shipped that).
+    int fresh = 0;
+    asm volatile("" : "+s"(fresh));
+    const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64 + fresh;
 #pragma unroll
     for (int ks = 0; ks < K0C; ++ks)
 #pragma unroll
@@ -624,22 +667,23 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     // inside the hidden GEMM into the same registers (gemm_hidden).  History: all requested after the epilogue, the hidden GEMM
     // waited for them (8.8 k cycles instead of 3.8 k at 2 dice x 6 faces).
     Frag t7h[kE1][kOTW], t7l[kE1][kOTW];
-    const f32x4* wt = w1 + (size_t)kRes * kOTW * 2 * 64;
-    asm volatile("" : "+s"(wt));  // a fresh load every group
-    auto fetch_tail = [&](auto lo_tag, auto hi_tag, auto slot0_tag) {  // streamed k-steps [lo, hi) -> slots slot0 ..
+    int fresh_t = 0;
+    asm volatile("" : "+s"(fresh_t));  // a fresh load every group (an opaque offset: see fetch_w0)
+    const f32x4* wt = w1 + (size_t)kRes * kOTW * 2 * 64 + fresh_t;
+    auto fetch_tail = [&](const f32x4* base, auto lo_tag, auto hi_tag, auto slot0_tag) {  // streamed k-steps [lo, hi) -> slots slot0 ..
 #pragma unroll
       for (int ks = decltype(lo_tag)::value; ks < decltype(hi_tag)::value; ++ks)
 #pragma unroll
         for (int ot = 0; ot < kOTW; ++ot) {
           const int sl = ks - decltype(lo_tag)::value + decltype(slot0_tag)::value;
-          t7h[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-          if (PROD >= 2) t7l[sl][ot].v = wt[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+          t7h[sl][ot].v = base[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+          if (PROD >= 2) t7l[sl][ot].v = base[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
         }
     };
     using I0 = std::integral_constant<int, 0>;
     using IE = std::integral_constant<int, kEarly>;
     using IT = std::integral_constant<int, kTail>;
-    fetch_tail(I0{}, IE{}, I0{});
+    fetch_tail(wt, I0{}, IE{}, I0{});
     RBL_NSTAMP();  // 3
     epilogue_regs(std::false_type{}, m.inv_scale[0], prm);
     RBL_NSTAMP();  // 4: L0 epilogue
@@ -649,8 +693,16 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     if constexpr (kTail == 0)
       gemm_resident<kRes, 0, 1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc);
     else
-      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(IE{}, IT{}, I0{}); });
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt, IE{}, IT{}, I0{}); });
     RBL_NSTAMP();  // 5: hidden gemm
+    if constexpr (NH == 2) {
+      // ------------------------------------------------------------ second hidden layer: the same half-resident scheme
+      const f32x4* wt2 = w2 + (size_t)kRes * kOTW * 2 * 64 + fresh_t;
+      fetch_tail(wt2, I0{}, IE{}, I0{});  // into the registers the first hidden layer's streamed k-steps just left
+      epilogue_regs(std::false_type{}, m.inv_scale[1], prm + 768);
+      init_acc(prm + 2 * 768);
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w2h, w2l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt2, IE{}, IT{}, I0{}); });
+    }
     if (kEarlyStage) {
       // the next group's queries (requested a whole group ago) become B fragments now: Xq was last read by this group's layer-0
       // GEMM, two barriers back, and the two barriers of the epilogue below order these stores before the next group's
@@ -659,7 +711,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       fetch_queries(grp + 2 * (int)gridDim.x);
     }
     RBL_NSTAMP();  // 6
-    epilogue_regs(std::true_type{}, m.inv_scale[1], prm + 768);
+    epilogue_regs(std::true_type{}, m.inv_scale[NH], prm + NH * 768);
     RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
     // with three or four input chunks (48 / 64 KB per CU) the request goes out AFTER the output stores below: VMEM issues in
     // order, and behind 64 KB of weight loads the stores (and the waves issuing them) waited ~2 k cycles
@@ -681,7 +733,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
         const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
         float* og = out + row0 * n_out;
-        const f32x4 r4 = o * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + col);
+        const f32x4 r4 = o * m.inv_scale[NH + 1] + *reinterpret_cast<const f32x4*>(prm + kOutBias + col);
         if (r_in < rows_here) {
           if ((n_out & 1) == 0) {  // even row length: a lane's four columns are two 8-byte aligned pairs (half the stores)
             f32x2* p2 = reinterpret_cast<f32x2*>(og + r_in * n_out + col);
@@ -727,7 +779,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         asm volatile("" : "+v"(r_in), "+v"(col));
         const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
         float* og = out + row0 * n_out;
-        const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[2] + *reinterpret_cast<const f32x4*>(prm + 1536 + ot * 16 + col);
+        const f32x4 r4 = (o + P[rt * 64 + lane]) * m.inv_scale[NH + 1] + *reinterpret_cast<const f32x4*>(prm + kOutBias + ot * 16 + col);
         if (r_in < rows_here) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -749,7 +801,9 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 }  // namespace
 
 bool mlp_resident_supported(int n_layers, int n_in, int n_hidden, int n_out) {
-  return n_layers == 2 && n_hidden == 256 && n_in >= 1 && n_in <= 128 && n_out >= 1 && n_out <= 64;
+  if (n_hidden != 256 || n_in < 1 || n_out < 1) return false;
+  if (n_layers == 2) return n_in <= 128 && n_out <= 64;
+  return n_layers == 3 && n_in <= 64 && n_out <= 16;  // two hidden layers: the second one streams (gemm_ring)
 }
 
 void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, float* out, hipStream_t stream,
@@ -765,9 +819,16 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   const int cus = dev < 64 ? n_cu[dev] : 256;
   const int n_groups = (int)((rows + kRows - 1) / kRows);
   const int grid = n_groups < cus ? n_groups : cus;
-#define RBL_RES3(K0C_, LN_, NOT_, PROD_)                                                                                  \
-  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, rows, \
-                   out, n_groups, range)
+#define RBL_RES4(K0C_, LN_, NOT_, PROD_, NH_)                                                                                  \
+  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_, NH_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
+                   rows, out, n_groups, range)
+  // two hidden layers (n_layers = 3): built for one or two input chunks (every one-die game and 2 dice x 3 faces)
+#define RBL_RES3(K0C_, LN_, NOT_, PROD_)                                                                      \
+  do {                                                                                                        \
+    if (m.n_layers == 2) RBL_RES4(K0C_, LN_, NOT_, PROD_, 1);                                                 \
+    else if constexpr (K0C_ <= 2 && NOT_ == 1) RBL_RES4(K0C_, LN_, NOT_, PROD_, 2);                           \
+    else throw std::runtime_error("launch_mlp_resident: n_layers = 3 needs n_in <= 64 and n_out <= 16");      \
+  } while (0)
   // the half_inference modes (MlpDev::products 2 / 1) are built for LayerNorm nets only (the reference's configuration)
 #define RBL_RES2(K0C_, LN_, NOT_)                                             \
   do {                                                                        \
@@ -790,6 +851,7 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   } while (0)
   const int variant = m.out_tiles == 1 ? 1 : (m.out_tiles <= 3 ? 3 : 4);
   if (m.out_tiles < 1 || m.out_tiles > 4) throw std::runtime_error("launch_mlp_resident: unsupported n_out");
+  if (m.n_layers != 2 && m.n_layers != 3) throw std::runtime_error("launch_mlp_resident: unsupported n_layers");
   switch (m.l0_chunks) {
     case 1: RBL_RES(1); break;
     case 2: RBL_RES(2); break;
@@ -799,6 +861,7 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
 #undef RBL_RES
 #undef RBL_RES2
 #undef RBL_RES3
+#undef RBL_RES4
 }
 
 }  // namespace rbl

@@ -37,10 +37,10 @@ def test_resident_net_kernel_instantiations_that_are_launched_do_not_spill():
     res = _resources("net_resident_kernel.hip")
     seen = 0
     for name, r in res.items():
-        m = re.search(r"mlp_resident_kernelILi(\d)ELb([01])ELi(\d)ELi(\d)E", name)
+        m = re.search(r"mlp_resident_kernelILi(\d)ELb([01])ELi(\d)ELi(\d)ELi(\d)E", name)
         if not m:
             continue
-        k0c, ln, notv, prod = (int(x) for x in m.groups())
+        k0c, ln, notv, prod, nh = (int(x) for x in m.groups())
         seen += 1
         # shapes no game reaches: one or two input chunks (n_in <= 64: at most 2 dice x 4 faces, 16 hands) with more than one
         # output tile (> 16 hands)
@@ -48,7 +48,24 @@ def test_resident_net_kernel_instantiations_that_are_launched_do_not_spill():
         assert r["vgprs"] <= 256
         if not unreachable:
             assert r["scratch"] == 0, (name, r)
-    assert seen >= 48  # 4 input-chunk counts x (LayerNorm on / off) x 3 output variants, + the two half_inference modes
+    # 4 input-chunk counts x (LayerNorm on / off) x 3 output variants, + the two half_inference modes; + two hidden layers
+    # (n_layers = 3) for one / two input chunks and one output tile
+    assert seen >= 56
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_resident_net_kernel_has_no_flat_loads(tmp_path):
+    """A pointer that passes through an asm operand comes back generic and hipcc emits FLAT loads for it; those count on
+    lgkmcnt too, so every LDS wait behind them also waits for an L2 round trip (rounds 2-4 shipped the per-group weight
+    fetches that way; the streamed k-steps of the 2 dice x 6 faces kernel sat inside its hidden GEMM)."""
+    out = tmp_path / "net_resident.s"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I../../include", "-Wno-unused-result", "-S",
+           "--cuda-device-only", "net_resident_kernel.hip", "-o", str(out)]
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    text = out.read_text()
+    assert "v_mfma_f32_16x16x32" in text
+    assert "flat_load" not in text and "flat_store" not in text
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")

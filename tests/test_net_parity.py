@@ -58,6 +58,18 @@ def test_mlp_vs_float64_reference(d, f, hidden, layers_n, use_ln, rows):
     _check_mlp(d, f, hidden, layers_n, use_ln, rows)
 
 
+def test_class_default_depth_runs_on_the_resident_kernel():
+    """Net2's class default is n_layers = 3 (cfvpy/models.py:73).  The register-resident kernel takes it (two hidden layers,
+    each half resident, half streamed) for the one-die games and 2 dice x 3 faces; results within the same 1e-5."""
+    for d, f in ((1, 6), (1, 4), (2, 3)):
+        e, err = _check_mlp(d, f, 256, 3, True, 40001, return_engine=True)
+        assert e.stats()["net_kernel"] == 5
+        assert err <= 2e-6
+    # 2 dice x 6 faces (four input chunks) and half_inference arithmetic at this depth: the engine says which kernel it picked
+    e, _ = _check_mlp(2, 6, 256, 3, True, 3000, return_engine=True)
+    assert e.stats()["net_kernel"] == 3
+
+
 def test_unsupported_net_shape_is_refused_loudly():
     """Only n_hidden = 256 nets run on the MFMA forward; anything else raises (the rela layer then falls back to the
     caller's TorchScript module on the GPU, never to a CPU path)."""
@@ -78,12 +90,12 @@ def test_mlp_edge_batches():
 
 def test_mlp_fallback_kernel(monkeypatch):
     """The feature-split kernel (RBL_MLP_TILE=3) is the fallback for shapes the resident kernel does not take
-    (n_layers != 2): same tolerance on the default shape too."""
+    (n_layers > 3, or n_layers = 3 at 2 dice x 6 faces): same tolerance on the default shape too."""
     monkeypatch.setenv("RBL_MLP_TILE", "3")
     _check_mlp(1, 6, 256, 2, True, 5000)
 
 
-def _check_mlp(d, f, hidden, layers_n, use_ln, rows, precision=0, atol=ATOL):
+def _check_mlp(d, f, hidden, layers_n, use_ln, rows, precision=0, atol=ATOL, return_engine=False):
     e = _engine(d, f)
     e.set_net_precision(precision)
     rng = np.random.default_rng(hidden + rows)
@@ -113,6 +125,8 @@ def _check_mlp(d, f, hidden, layers_n, use_ln, rows, precision=0, atol=ATOL):
     ref = _np_net(q, layers, ln, w_out, b_out)
     assert np.abs(ref).max() > 0.05  # O(0.1-1) outputs: the tolerance is meaningful
     assert np.abs(y - ref).max() <= atol, np.abs(y - ref).max()
+    if return_engine:
+        return e, np.abs(y - ref).max()
     return np.abs(y - ref).max()
 
 
