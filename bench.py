@@ -559,7 +559,7 @@ def main():
                 rp["frac"] = rp["achieved"] / out[key]["peak"]
                 out[key]["rocprof"] = rp
         if power.get("headline"):
-            # the dominant kernel is socket-power-bound (84 % of the step at ~1.39 kW of a 1.4 kW cap): see DESIGN.md 3.2d
+            # the dominant kernel is socket-power-bound (84 % of the step at ~1.39 kW of a 1.4 kW cap): see DESIGN.md 3.4
             out["power"] = power["headline"]
         if per_rank:
             if a.share_gpu:

@@ -65,7 +65,7 @@ void Engine::construct() {
   // Lane parts on separate streams: with >= 16384 lanes the launches are long enough that one stream (net forward over
   // all lanes, then the CFR step over all lanes) loses only ~3 % to kernel tails and launch gaps, and every kernel then
   // runs with the GPU to itself (measured durations are the kernels' own); smaller batches gain 5-7 % from two
-  // interleaved half-batches whose tails overlap (4096 lanes: 38.6 vs 36.3 M it/s, 8192: 42.4 vs 40.3; DESIGN.md 3.2b).
+  // interleaved half-batches whose tails overlap (4096 lanes: 38.6 vs 36.3 M it/s, 8192: 42.4 vs 40.3; DESIGN.md 3.6).
   max_parts_ = std::min(4, std::max(1, env_int("RBL_PARTS", max_lanes_ >= 16384 ? 1 : 2)));
   RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_ready_, hipEventDisableTiming));
   for (int i = 0; i < 3; ++i) RBL_HIP_CHECK(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));

@@ -9,7 +9,7 @@
 // n_hidden = 256); this file holds the general n_hidden = 256 kernel ("feature split", any n_layers <= 7) that serves
 // the shapes the resident kernel does not take, plus the host-side weight packing of both.  Both evaluate every
 // product as an f16 x 2 split on v_mfma_f32_16x16x32_f16 (see below).  The earlier f32-MFMA and LDS-tape designs that
-// led here are described in DESIGN.md section 3.2; their code was removed in round 2.
+// led here are described in HISTORY.md section 3.2; their code was removed in round 2.
 #include "net_kernels.h"
 
 #include <cmath>

@@ -17,7 +17,7 @@ e.set_net_synthetic()
 rng = np.random.default_rng(0)
 # self-play visits public states along games: a third of the lanes at the root, the rest spread over the bids (measured mix
 # of the bench: ~30 % root-sized trees)
-bids = np.where(rng.random(B) < 0.3, -1, rng.integers(0, e.A - 2, B)).astype(np.int32)
+bids = np.where(rng.random(B) < (2.0 if os.environ.get('RBL_PROBE_ROOT') else 0.3), -1, rng.integers(0, e.A - 2, B)).astype(np.int32)
 e.reset(bids, (bids + 1) % 2 * 0, rng.dirichlet(np.ones(e.H), size=(B, 2)))
 e.multistep(steps)
 e.sync()

@@ -1,5 +1,5 @@
 """Compile-time resource guard for the two hot kernels (CPU only: hipcc cross-compiles gfx950 without a GPU).  A scratch spill
-in the resident value-net kernel is a memory round trip inside its GEMM phases (it cost 9 k cycles per group
+in the resident value-net kernel is a memory round trip inside its GEMM phases (HISTORY.md 3.2: it cost 9 k cycles per group
 once), and the one-wavefront CFR kernel needs <= 128 VGPRs for its four waves per SIMD -- both were lost and recovered more than
 once while the kernels were being changed, so the build checks them."""
 import os

@@ -3,7 +3,7 @@ torch-CPU `Net2` -- cannot be bit-exact (the two forwards differ by ~1e-7 per ca
 beyond ~128 iterations, on the reference against itself too: SURVEY section 7).  What is pinned here instead:
   * element-wise agreement (1e-5, the north-star tolerance) through the first 128 iterations of a subgame for the
     default-initialised net (outputs x0.01, cfvpy/models.py:89-91); with O(0.3) outputs (x30) the amplification sets in
-    earlier -- measured on MI355X (scripts/attic/p3_probe.py): sigma_last 4.9e-6 at 16 iterations, 3.8e-4 at 64, O(0.1) at
+    earlier -- measured on MI355X (a one-off probe, git show 6e16c1c:scripts/attic/p3_probe.py): sigma_last 4.9e-6 at 16 iterations, 3.8e-4 at 64, O(0.1) at
     128 -- so there the element-wise claim is made through 16 iterations and only the root values (running means, robust)
     are followed further;
   * whole self-play trajectories at 128 iterations per subgame (default-init net): same public states, examples
