@@ -35,6 +35,8 @@ struct CfrArgs {
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
   const int8_t* wave_tabs;  // cfr_wave_kernel: per shape parent | act | cb | ce | depth | irank (N bytes each) | leaf nodes (L) |
   const int* wave_tab_off;  //                  terminal nodes (T) as one 4-byte aligned blob; byte offset of each shape's blob
+  const unsigned short* wave_epv;  // cfr_wave_kernel: per shape, per edge element (c - 1) * H + h: parent(c) * H + h
+  const int* wave_epv_off;         //                  element offset of each shape's table
   int H, A, Q, faces, dice;
   int Emax, Nmax;         // per-lane strides: Emax*H reals per strategy array
   // ---- per-lane descriptors

@@ -308,12 +308,26 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   double* rho_t = t == root_player ? rho_rp : rho_op;
   const int tmul = t == root_player ? 1 : 0;
   // Per-thread view of a traverser level's edge elements i = tid + 64 u (element = (child c, hand h) of the level below):
-  // its regret and strategy-sum values (requested from global memory up front), the LDS offsets of its parent's value /
-  // reach row.  The regret update, the normalisation and the strategy-sum update all walk this same element set, so the
-  // index arithmetic is done once.  Depth-2 subgames have exactly one traverser level; for deeper trees the arrays of
-  // the LAST processed (shallowest) one stay alive for the write-back and the others are redone there.
-  double rq[KS], gs_[KS];
-  int pv[KS], pr[KS];
+  // its regret and strategy-sum values (requested from global memory up front) and the LDS offset pv = parent * H + h of its
+  // parent's value row -- which is also the offset of the parent's reach row and row-sum row (a parent has children, so its
+  // reach-row rank is its node id).  pv comes from a per-shape table (one 2-byte load next to the regret load; it used to be a
+  // division by H, a modulo, a byte-table look-up and a multiply-add per element).  The regret update, the normalisation and
+  // the strategy-sum update all walk this same element set.  Depth-2 subgames have exactly one traverser level; for deeper
+  // trees the arrays of the LAST processed (shallowest) one stay alive for the write-back and the others are redone there.
+  // K: how many 64-element strides the traverser's widest level needs -- ONE wave-uniform choice among thirds of the maximum
+  // (the same idea as the sigma staging): when the traverser owns the 12 root edges (72 elements at 1 die x 6 faces) the other
+  // 6-7 strides used to issue their clamped loads and exec-mask branches for nothing in every pass.  Only the strides of the
+  // last third can reach past the level (K is the smallest third that covers it).
+  constexpr int KS3 = (KS + 2) / 3, KS23 = (2 * KS + 2) / 3;
+  int ch_max = 0;
+  for (int lev = nlev - 2; lev >= 0; --lev)
+    if ((root_player ^ (lev & 1)) == t) ch_max = max(ch_max, (shc->lev_off[lev + 2] - shc->lev_off[lev + 1]) * H);
+  const unsigned short* epv = a.wave_epv + ((cint_p)a.wave_epv_off)[((cint_p)a.lane_shape)[lane]];
+  auto tail = [&](auto kc) {
+  constexpr int K = decltype(kc)::value;
+  constexpr int KFULL = K > KS3 ? K - KS3 : 0;  // strides that lie wholly inside the level
+  double rq[K], gs_[K];
+  int pv[K];
   int lev_kept = -1;
   for (int lev = nlev - 2; lev >= 0; --lev) {
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
@@ -323,13 +337,11 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     if (mine) {
       lev_kept = lev;
 #pragma unroll
-      for (int u = 0; u < KS; ++u) {
-        const int i = max(0, min(tid + u * W, ch - 1));
+      for (int u = 0; u < K; ++u) {
+        const int i = u < KFULL && ch == ch_max ? tid + u * W : max(0, min(tid + u * W, ch - 1));
         rq[u] = g_reg[(c_lo - 1) * H + i];
         gs_[u] = g_sum[(c_lo - 1) * H + i];
-        const int p = t_parent[c_lo + i / H], h = i % H;
-        pv[u] = p * H + h;
-        pr[u] = irank(p) * H + h;
+        pv[u] = epv[(c_lo - 1) * H + i];
       }
     }
     for (int i = tid; i < nh; i += W) {  // node value of (n, h): sequential over the actions, ascending
@@ -367,9 +379,9 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     double* greg = g_reg + (c_lo - 1) * H;
     const double* lval = val + c_lo * H;
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {  // regret update + regret matching numerators, one thread per edge element
+    for (int u = 0; u < K; ++u) {  // regret update + regret matching numerators, one thread per edge element
       const int i = tid + u * W;
-      if (i < ch) {
+      if ((u < KFULL && ch == ch_max) || i < ch) {
         double q = rq[u];
         q += lval[i];
         q -= val[pv[u]];
@@ -377,19 +389,10 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         greg[i] = q * (q > 0 ? a.pos : a.neg);
       }
     }
-    for (int i = tid + KS * W; i < ch; i += W) {  // levels wider than the template bound (not expected)
-      const int pp = t_parent[c_lo + i / H], h = i % H;
-      double q = greg[i];
-      q += lval[i];
-      q -= val[pp * H + h];
-      lsig[i] = q > kEps ? q : kEps;
-      greg[i] = q * (q > 0 ? a.pos : a.neg);
-    }
     wave_sync();
     // the children's values have been consumed (regret update above): their rows now hold the row sums, one row per node
     // of this level that has children (those nodes' reach-row ranks are consecutive; every one of them has >= 1 child)
     double* ysum = val + c_lo * H;
-    const int irk0 = irank(n0);
     for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
@@ -403,21 +406,16 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         if (c + 2 < c1) s += s2;
         if (c + 3 < c1) s += s3;
       }
-      ysum[(irank(n) - irk0) * H + h] = s;
+      ysum[(n - n0) * H + h] = s;  // (a node with children: its reach-row rank is its node id)
     }
     wave_sync();
 #pragma unroll
-    for (int u = 0; u < KS; ++u) {
+    for (int u = 0; u < K; ++u) {
       const int i = tid + u * W;
-      if (i < ch) {
-        const double s = ysum[pr[u] - irk0 * H];
+      if ((u < KFULL && ch == ch_max) || i < ch) {
+        const double s = ysum[pv[u] - n0 * H];
         lsig[i] = div_by(lsig[i], s, refine_rcp(s));
       }
-    }
-    for (int i = tid + KS * W; i < ch; i += W) {
-      const int ir = irank(t_parent[c_lo + i / H]), h = i % H;
-      const double s = ysum[(ir - irk0) * H + h];
-      lsig[i] = div_by(lsig[i], s, refine_rcp(s));
     }
     wave_sync();
   }
@@ -449,28 +447,36 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     const int ch = (c_hi - c_lo) * H, e0 = (c_lo - 1) * H;
     if (lev == lev_kept) {
 #pragma unroll
-      for (int u = 0; u < KS; ++u) {
+      for (int u = 0; u < K; ++u) {
         const int i = tid + u * W;
-        if (i < ch) {
+        if ((u < KFULL && ch == ch_max) || i < ch) {
           const double sg = sig[e0 + i];
           double x = gs_[u];
           x *= a.strat;
-          x += rho_t[tmul ? pr[u] : (tid + u * W) % H] * sg;
+          x += rho_t[tmul ? pv[u] : (tid + u * W) % H] * sg;
           g_sum[e0 + i] = x;
           g_sig[e0 + i] = sg;
         }
       }
-    }
-    for (int i = tid + (lev == lev_kept ? KS * W : 0); i < ch; i += W) {
-      const int ir = irank(t_parent[c_lo + i / H]), h = i % H;
-      const double sg = sig[e0 + i];
-      double x = g_sum[e0 + i];
-      x *= a.strat;
-      x += rho_t[ir * tmul * H + h] * sg;
-      g_sum[e0 + i] = x;
-      g_sig[e0 + i] = sg;
+    } else {  // (only trees deeper than this kernel takes have a second traverser level)
+      for (int i = tid; i < ch; i += W) {
+        const int ir = irank(t_parent[c_lo + i / H]), h = i % H;
+        const double sg = sig[e0 + i];
+        double x = g_sum[e0 + i];
+        x *= a.strat;
+        x += rho_t[ir * tmul * H + h] * sg;
+        g_sum[e0 + i] = x;
+        g_sig[e0 + i] = sg;
+      }
     }
   }
+  };
+  if (ch_max <= KS3 * W)
+    tail(std::integral_constant<int, KS3>{});
+  else if (ch_max <= KS23 * W)
+    tail(std::integral_constant<int, KS23>{});
+  else
+    tail(std::integral_constant<int, KS>{});
   if (snap_now) {
     double* snap = a.snapshot + lane_e;
     for (int i = tid; i < EH; i += W) snap[i] = sig[i];

@@ -124,6 +124,17 @@ void Engine::construct() {
     blob.resize(blob.size() + kWavePad, 0);
     d_wave_tabs_.upload(blob, stream_);
     d_wave_tab_off_.upload(off, stream_);
+    // per edge element (c - 1) * H + h of a shape: the LDS offset parent(c) * H + h of its parent's value / reach / row-sum row
+    std::vector<unsigned short> epv;
+    std::vector<int> epv_off;
+    for (const ShapeDev& s : tabs_.shapes) {
+      epv_off.push_back((int)epv.size());
+      for (int c = 1; c < s.N; ++c)
+        for (int h = 0; h < g_.H; ++h) epv.push_back((unsigned short)(tabs_.parent[s.node_off + c] * g_.H + h));
+    }
+    epv.resize(epv.size() + kWavePad, 0);
+    d_wave_epv_.upload(epv, stream_);
+    d_wave_epv_off_.upload(epv_off, stream_);
     RBL_HIP_CHECK(hipStreamSynchronize(stream_));  // blob / off go out of scope
   }
   std::vector<int8_t> m((size_t)g_.faces * g_.H + kWavePad);
@@ -189,6 +200,7 @@ void Engine::construct() {
       for (int n = 0; n < s.N; ++n)
         if (tabs_.irank[s.node_off + n] != (n < s.NI ? n : -1)) prefix_ok = false;
     }
+    wave_lds_bytes_ += (size_t)std::max(0, env_int("RBL_WAVE_LDS_EXTRA", 0));  // developer aid: occupancy experiments
     wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 && prefix_ok &&
                cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
   }
@@ -786,6 +798,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.matches = d_matches_.p;
   a.wave_tabs = d_wave_tabs_.p;
   a.wave_tab_off = d_wave_tab_off_.p;
+  a.wave_epv = d_wave_epv_.p;
+  a.wave_epv_off = d_wave_epv_off_.p;
   a.H = g_.H;
   a.A = g_.A;
   a.Q = g_.query_size();
