@@ -107,7 +107,8 @@ bool launch_cfr_rows(const CfrArgs& a, int B, int block, size_t lds_bytes, hipSt
 // its staging loads are unconditional: every global array it reads must be padded by this many ELEMENTS behind the last
 // one a lane owns (sigma / values / the per-node and leaf tables / the match table)
 constexpr size_t kWavePad = 2048;
-size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces);
+// lo_d / lo_p: first node of the deepest level / of its parents' level (ShapeDev::lev_off[nlev - 1], [nlev - 2])
+size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces, int lo_d, int lo_p);
 bool cfr_wave_supported(int H, int A, int dice, int faces, int max_EH, int max_LH, int max_N);
 bool launch_cfr_wave(const CfrArgs& a, int B, size_t lds_bytes, hipStream_t stream);
 // the same kernel for lanes whose state does not fit LDS (2 dice x 6 faces): node values and reach rows in LDS, sigma /

@@ -97,23 +97,33 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   const bool snap_now = a.lane_act_iter && ((cint_p)a.lane_act_iter)[lane] == a.steps_after;
 
   // ---- LDS layout
-  double* sig = lds;                 // [E][H]
-  double* val = sig + EH;            // [N][H]
+  // Node values.  A pseudo-leaf's value is a float by construction ((double)(float)(net row x reach sum), :257-268), and
+  // pseudo-leaves only exist on the DEEPEST level (a node above max_depth that is not terminal has children): that level's rows
+  // are stored as floats, indexed by node (the slots of its terminals stay unused).  A terminal of the deepest level is the
+  // LAST child of its parent (the liar call is the highest action; the host checks both facts per shape): its fp64 row is
+  // kept per PARENT.  Everything above the deepest level keeps an fp64 row per node.  8.7 KB per root lane instead of 10.0 KB at
+  // 1 die x 6 faces = 18 lanes per CU instead of 16 (12.7 instead of 14.7 KB at 2 dice x 3 faces: 12 instead of 10).
+  const int lo1 = shc->lev_off[1], lo2 = shc->lev_off[2];
+  const int lo_d = nlev == 3 ? lo2 : lo1, lo_p = nlev == 3 ? lo1 : 0;  // first node of the deepest level / of its parents' level
+  const int NP = lo_d - lo_p, ND = N - lo_d;
+  double* sig = lds;                  // [E][H]
+  double* vald = sig + EH;            // [lo_d][H]   values of the nodes above the deepest level
+  double* vterm = vald + lo_d * H;    // [NP][H]     value of the terminal child of deepest-level parent p at row p - lo_p
   // Reach rows are kept for the nodes that have children.  In a tree of depth <= 2 (all this kernel takes) only the ROOT's
   // mover has a reach that differs between those rows; the other player's reach is the same at the root and at every depth-1
   // node (it moves at depth 1, i.e. into nodes that keep no row): one row instead of NI.
-  double* rho_rp = val + N * H;      // [NI][H] reach of the root's mover
-  double* rho_op = rho_rp + NI * H;  // [1][H]  reach of the other player
+  double* rho_rp = vterm + NP * H;    // [NI][H] reach of the root's mover
+  double* rho_op = rho_rp + NI * H;   // [1][H]  reach of the other player
+  float* valf = reinterpret_cast<float*>(rho_op + H);  // [ND][H] floats: pseudo-leaf values of the deepest level, row c - lo_d
   auto rrow = [&](int pl, int ir) -> double* { return pl == root_player ? rho_rp + ir * H : rho_op; };
   // nodes with children are a prefix of the BFS order here (the host checks it), and a node's depth follows from the level
   // offsets: no irank / depth tables
-  const int lo1 = shc->lev_off[1], lo2 = shc->lev_off[2];
   auto irank = [&](int n) { return n < NI ? n : -1; };
   auto dpar = [&](int n) { return ((n >= lo1) + (n >= lo2)) & 1; };
-  // (the regret-matching row sums live in the value rows of the level they normalise, which are dead by then; their
-  // refined reciprocals are recomputed where they are used: 10.6 KB per root lane instead of 12.1 KB = 15 lanes per CU)
+  // (the regret-matching row sums live in value rows that are dead by then -- the terminal rows of the level they normalise, or
+  // the depth-1 rows when the root is normalised; their refined reciprocals are recomputed where they are used)
   // tree tables as bytes: every entry is a node id, an action, a row index or -1, all < 128 for these games (NM <= 127)
-  int8_t* tb = reinterpret_cast<int8_t*>(rho_op + H);
+  int8_t* tb = reinterpret_cast<int8_t*>(valf + ((ND * H + 1) & ~1));
   int8_t *t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N;
   int8_t *t_leaf = tb + 4 * N, *t_term = t_leaf + L;  // t_leaf[k]: node of net row k; t_term[j]: j-th terminal
   int8_t* t_match = t_term + T;
@@ -246,20 +256,20 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     const int k = tid + u * W;
     if (k < L) {
       const int n = t_leaf[k];
-      const Row<H> ro = n == 0 ? load_row<H>(rrow(opp, 0)) : opp_reach_row(n);
+      const Row<H> ro = opp_reach_row(n);  // (n >= 1: the host only sends trees whose root has children)
       double ssum = 0.0;
 #pragma unroll
       for (int h = 0; h < H; ++h) ssum += ro.v[h];
-      Row<H> out;
+      float* out = valf + (n - lo_d) * H;
 #pragma unroll
-      for (int h = 0; h < H; ++h) out.v[h] = (double)(float)((double)lv_[u][h] * ssum);
-      store_row<H>(val + n * H, out);
+      for (int h = 0; h < H; ++h) out[h] = (float)((double)lv_[u][h] * ssum);
     }
   }
   for (int j = tid; j < T; j += W) {  // terminals: the bid that was called is the parent's last bid (:80-98, :765-789)
     const int n = t_term[j];
-    const Row<H> ro = n == 0 ? load_row<H>(rrow(opp, 0)) : opp_reach_row(n);
-    const int bid = n == 0 ? 0 : t_act[t_parent[n]];
+    const Row<H> ro = opp_reach_row(n);
+    const int par = t_parent[n];
+    const int bid = t_act[par];
     const int qty = 1 + bid / FACES, face = bid % FACES;
     const int8_t* m = t_match + face * H;
     double b[NB];
@@ -295,7 +305,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       for (int mm = 1; mm <= DICE; ++mm) x = (mh == mm) ? cand[mm] : x;
       out.v[h] = x;
     }
-    store_row<H>(val + n * H, out);
+    store_row<H>(n >= lo_d ? vterm + (par - lo_p) * H : vald + n * H, out);
   }
   wave_sync();
   RBL_STAMP();  // 2: reach + leaf values
@@ -344,6 +354,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
         pv[u] = epv[(c_lo - 1) * H + i];
       }
     }
+    const bool deep = lev + 2 == nlev;  // the children are the deepest level: float rows + one terminal row per parent
     for (int i = tid; i < nh; i += W) {  // node value of (n, h): sequential over the actions, ascending
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
@@ -351,40 +362,78 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       // the additions stay sequential in ascending action order; the LDS reads of four actions are issued together
       // (reads past the node's last child land in other rows of the lane's LDS image and are never added)
       double x = 0.0;
-      const double* pv_ = val + c0 * H + h;
       const double* ps_ = sig + (c0 - 1) * H + h;
-      if (mine) {
-        for (int c = c0; c < c1; c += 4, pv_ += 4 * H, ps_ += 4 * H) {
-          const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
-          const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
-          x += v0 * s0;
-          if (c + 1 < c1) x += v1 * s1;
-          if (c + 2 < c1) x += v2 * s2;
-          if (c + 3 < c1) x += v3 * s3;
+      if (deep) {
+        const bool has_term = t_act[c1 - 1] == A - 1;  // the liar call, always the last child
+        const int cl = c1 - (has_term ? 1 : 0);        // the children before it are pseudo-leaves
+        const float* pf_ = valf + (c0 - lo_d) * H + h;
+        if (mine) {
+          for (int c = c0; c < cl; c += 4, pf_ += 4 * H, ps_ += 4 * H) {
+            const float v0 = pf_[0], v1 = pf_[H], v2 = pf_[2 * H], v3 = pf_[3 * H];
+            const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
+            x += (double)v0 * s0;
+            if (c + 1 < cl) x += (double)v1 * s1;
+            if (c + 2 < cl) x += (double)v2 * s2;
+            if (c + 3 < cl) x += (double)v3 * s3;
+          }
+          if (has_term) x += vterm[(n - lo_p) * H + h] * sig[(c1 - 2) * H + h];
+        } else {
+          for (int c = c0; c < cl; c += 4, pf_ += 4 * H) {
+            const float v0 = pf_[0], v1 = pf_[H], v2 = pf_[2 * H], v3 = pf_[3 * H];
+            x += (double)v0;
+            if (c + 1 < cl) x += (double)v1;
+            if (c + 2 < cl) x += (double)v2;
+            if (c + 3 < cl) x += (double)v3;
+          }
+          if (has_term) x += vterm[(n - lo_p) * H + h];
         }
       } else {
-        for (int c = c0; c < c1; c += 4, pv_ += 4 * H) {
-          const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
-          x += v0;
-          if (c + 1 < c1) x += v1;
-          if (c + 2 < c1) x += v2;
-          if (c + 3 < c1) x += v3;
+        const double* pv_ = vald + c0 * H + h;
+        if (mine) {
+          for (int c = c0; c < c1; c += 4, pv_ += 4 * H, ps_ += 4 * H) {
+            const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
+            const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
+            x += v0 * s0;
+            if (c + 1 < c1) x += v1 * s1;
+            if (c + 2 < c1) x += v2 * s2;
+            if (c + 3 < c1) x += v3 * s3;
+          }
+        } else {
+          for (int c = c0; c < c1; c += 4, pv_ += 4 * H) {
+            const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
+            x += v0;
+            if (c + 1 < c1) x += v1;
+            if (c + 2 < c1) x += v2;
+            if (c + 3 < c1) x += v3;
+          }
         }
       }
-      val[n * H + h] = x;
+      vald[n * H + h] = x;
     }
     wave_sync();
     if (!mine) continue;
     double* lsig = sig + (c_lo - 1) * H;
     double* greg = g_reg + (c_lo - 1) * H;
-    const double* lval = val + c_lo * H;
+    // the child's value: a float row or (flag of the element's table entry) its parent's terminal row on the deepest level,
+    // an fp64 row per node above it
+    const double* lval = vald + c_lo * H;
+    const double* ltrm = vterm - lo_p * H;
 #pragma unroll
     for (int u = 0; u < K; ++u) {  // regret update + regret matching numerators, one thread per edge element
       const int i = tid + u * W;
       if ((u < KFULL && ch == ch_max) || i < ch) {
         double q = rq[u];
-        q += lval[i];
-        q -= val[pv[u]];
+        const int po = pv[u] & 0x7fff;
+        double cv;
+        if (deep) {
+          const double ct = ltrm[po];
+          const double cf = (double)valf[i];
+          cv = (pv[u] & 0x8000) ? ct : cf;
+        } else {
+          cv = lval[i];
+        }
+        q += cv;
+        q -= vald[po];
         lsig[i] = q > kEps ? q : kEps;
         greg[i] = q * (q > 0 ? a.pos : a.neg);
       }
@@ -392,7 +441,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     wave_sync();
     // the children's values have been consumed (regret update above): their rows now hold the row sums, one row per node
     // of this level that has children (those nodes' reach-row ranks are consecutive; every one of them has >= 1 child)
-    double* ysum = val + c_lo * H;
+    double* ysum = deep ? vterm : vald + c_lo * H;  // [n - n0][H]
     for (int i = tid; i < nh; i += W) {  // row sums of (n, h), sequential over the actions
       const int n = n0 + i / H, h = i % H;
       const int c0 = t_cb[n], c1 = t_ce[n];
@@ -413,7 +462,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
     for (int u = 0; u < K; ++u) {
       const int i = tid + u * W;
       if ((u < KFULL && ch == ch_max) || i < ch) {
-        const double s = ysum[pv[u] - n0 * H];
+        const double s = ysum[(pv[u] & 0x7fff) - n0 * H];
         lsig[i] = div_by(lsig[i], s, refine_rcp(s));
       }
     }
@@ -424,7 +473,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
   // ---------------------------------------------------------------- running mean of the root values (:579-590)
   if (tid < H) {
     double m = rmean_t;
-    m += (val[tid] - m) * a.alpha;
+    m += (vald[tid] - m) * a.alpha;
     rmean[t * H + tid] = m;
   }
   // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638), rows of
@@ -453,7 +502,7 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
           const double sg = sig[e0 + i];
           double x = gs_[u];
           x *= a.strat;
-          x += rho_t[tmul ? pv[u] : (tid + u * W) % H] * sg;
+          x += rho_t[tmul ? (pv[u] & 0x7fff) : (tid + u * W) % H] * sg;
           g_sum[e0 + i] = x;
           g_sig[e0 + i] = sg;
         }
@@ -533,16 +582,25 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
 
 }  // namespace
 
-size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
-  const size_t d = (size_t)(N - 1) * H + (size_t)N * H + (size_t)(NI + 1) * H;  // doubles: sigma, values, reach rows
-  size_t b = d * 8 + (size_t)(4 * N + L + T) + (size_t)faces * H;
+size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces, int lo_d, int lo_p) {
+  // doubles: sigma, values above the deepest level, one terminal row per deepest-level parent, reach rows; floats: the
+  // deepest level's rows (kernel: "LDS layout")
+  const size_t d = (size_t)(N - 1) * H + (size_t)lo_d * H + (size_t)(lo_d - lo_p) * H + (size_t)(NI + 1) * H;
+  const size_t f = ((size_t)(N - lo_d) * H + 1) & ~(size_t)1;
+  const size_t v = d * 8 + f * 4;
+  size_t b = v + (size_t)(4 * N + L + T) + (size_t)faces * H;
   // the byte tables are staged as KT strides of 64 dwords (KT from the instantiation's NM, see launch_cfr_wave) and the
   // match table as one 64-byte store behind them: the image must hold whichever reaches further (1 die x 5 faces: the
   // 512-byte table store ends 40 bytes behind the slack of the layout itself)
   const int NM = H == 4 ? 45 : (H == 5 ? 66 : 91);
   const size_t KT = (size_t)(((5 * NM + 3) / 4 + 63) / 64);
-  b = std::max(b, d * 8 + KT * 256);
-  b = std::max(b, d * 8 + (size_t)(4 * N + L + T) + 64);
+  b = std::max(b, v + KT * 256);
+  b = std::max(b, v + (size_t)(4 * N + L + T) + 64);
+  // the sigma staging stores run up to a third of the stride count past the lane's own elements (kernel: "stage"): they must
+  // stay inside the image whatever follows sigma in it
+  const int EHM = H == 4 ? 176 : (H == 5 ? 325 : (H == 6 ? 540 : 810));
+  const size_t KS = (size_t)((EHM + 63) / 64);
+  b = std::max(b, ((size_t)(N - 1) * H + ((KS + 2) / 3) * 64) * 8);
   return ((b + 15) & ~(size_t)15) + kWaveLdsSlack;
 }
 

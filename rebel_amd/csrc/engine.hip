@@ -124,13 +124,14 @@ void Engine::construct() {
     blob.resize(blob.size() + kWavePad, 0);
     d_wave_tabs_.upload(blob, stream_);
     d_wave_tab_off_.upload(off, stream_);
-    // per edge element (c - 1) * H + h of a shape: the LDS offset parent(c) * H + h of its parent's value / reach / row-sum row
+    // per edge element (c - 1) * H + h of a shape: the LDS offset parent(c) * H + h (< 2^15) of its parent's value / reach / row-sum row
     std::vector<unsigned short> epv;
     std::vector<int> epv_off;
     for (const ShapeDev& s : tabs_.shapes) {
       epv_off.push_back((int)epv.size());
       for (int c = 1; c < s.N; ++c)
-        for (int h = 0; h < g_.H; ++h) epv.push_back((unsigned short)(tabs_.parent[s.node_off + c] * g_.H + h));
+        for (int h = 0; h < g_.H; ++h)  // bit 15: the child is a terminal (its value lives in its parent's terminal row)
+          epv.push_back((unsigned short)((tabs_.parent[s.node_off + c] * g_.H + h) | (tabs_.act[s.node_off + c] == g_.liar ? 0x8000 : 0)));
     }
     epv.resize(epv.size() + kWavePad, 0);
     d_wave_epv_.upload(epv, stream_);
@@ -191,14 +192,23 @@ void Engine::construct() {
     for (const ShapeDev& s : tabs_.shapes) {
       max_eh = std::max(max_eh, (s.N - 1) * g_.H);
       max_lh = std::max(max_lh, s.L * g_.H);
-      wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces));
+      if (s.nlev >= 2)
+        wave_lds_bytes_ = std::max(wave_lds_bytes_, cfr_wave_lds_bytes(s.N, s.NI, g_.H, s.L, s.T, g_.faces,
+                                                                        s.lev_off[s.nlev - 1], s.lev_off[s.nlev - 2]));
     }
     // the kernel's tree model: depth <= 2 and the nodes with children first in BFS order (reach-row rank = node id)
     bool prefix_ok = true;
     for (const ShapeDev& s : tabs_.shapes) {
-      if (s.nlev > 3) prefix_ok = false;
+      if (s.nlev > 3 || s.nlev < 2) prefix_ok = false;  // (nlev < 2: the root itself is a pseudo-leaf, max_depth = 0)
       for (int n = 0; n < s.N; ++n)
         if (tabs_.irank[s.node_off + n] != (n < s.NI ? n : -1)) prefix_ok = false;
+      // its value layout: pseudo-leaves only on the deepest level; a deepest-level terminal is the LAST child of its parent
+      const int lo_d = s.lev_off[std::max(s.nlev - 1, 0)];
+      for (int n = 0; n < s.N; ++n) {
+        if (tabs_.leaf_row[s.node_off + n] >= 0 && n < lo_d) prefix_ok = false;
+        if (n >= lo_d && tabs_.act[s.node_off + n] == g_.liar && n + 1 != tabs_.ce[s.node_off + tabs_.parent[s.node_off + n]])
+          prefix_ok = false;
+      }
     }
     wave_lds_bytes_ += (size_t)std::max(0, env_int("RBL_WAVE_LDS_EXTRA", 0));  // developer aid: occupancy experiments
     wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 && prefix_ok &&
