@@ -280,13 +280,20 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // loads per thread and the staging itself, not a wait -- they move, they do not shrink.)
   constexpr bool kEarlyStage = K0C <= 2;
   constexpr int kQImageBytes = kEarlyStage ? K0C * 2 * kRT * 64 * 16 : 0;
-  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes];
+  // kW0Lds (round 5, one input chunk): the layer-0 weights of every wave (4 KB each) are copied to LDS once per launch and read
+  // from there per group.  As global loads requested after the last epilogue they shared the vmcnt queue with the output
+  // stores issued right behind them, whose number the compiler cannot know: the first MFMA of the next group sat behind
+  // `s_waitcnt vmcnt(0)`, i.e. behind the store acknowledgements of the group that had just finished, in every group.
+  constexpr bool kW0Lds = K0C == 1;
+  constexpr int kW0LdsBytes = kW0Lds ? kWaves * K0C * kOTW * 2 * 64 * 16 : 0;
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes + kW0LdsBytes];
   f32x4* X = reinterpret_cast<f32x4*>(smem);                 // [ks][hi,lo][row tile][lane] B fragments
   unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
   float* S = reinterpret_cast<float*>(smem + kImageBytes);   // [row][wave] sums of squares
   f32x4* P = reinterpret_cast<f32x4*>(S + kRows * kWaves);   // [wave][row tile][lane] partial outputs (k slice of a wave)
   float* prm = reinterpret_cast<float*>(P + kWaves * kRT * 64);  // [layer][bias, gamma, beta'][256], output bias
   f32x4* Xq = kEarlyStage ? reinterpret_cast<f32x4*>(prm + kParamFloats) : X;  // B fragments of the query rows (layer 0's input)
+  f32x4* W0s = reinterpret_cast<f32x4*>(smem + kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes);
   unsigned long long* Xq8 = reinterpret_cast<unsigned long long*>(Xq);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
   const int lane0 = tid & 63;
@@ -606,15 +613,33 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     // reduction, the next GEMM's fragment ring) also waited for these L2 round trips (rounds 2-4 shipped that).
     int fresh = 0;
     asm volatile("" : "+s"(fresh));
-    const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64 + fresh;
+    if constexpr (kW0Lds) {  // this wave's copy in LDS (written below, before the first call)
+      const f32x4* w0 = W0s + wave * (K0C * kOTW * 2 * 64) + fresh;
 #pragma unroll
-    for (int ks = 0; ks < K0C; ++ks)
+      for (int ks = 0; ks < K0C; ++ks)
 #pragma unroll
-      for (int ot = 0; ot < kOTW; ++ot) {
-        th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
-        if (PROD >= 2) tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
-      }
+        for (int ot = 0; ot < kOTW; ++ot) {
+          th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+          if (PROD >= 2) tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        }
+    } else {
+      const f32x4* w0 = blob + (size_t)wave * K0C * kOTW * 2 * 64 + fresh;
+#pragma unroll
+      for (int ks = 0; ks < K0C; ++ks)
+#pragma unroll
+        for (int ot = 0; ot < kOTW; ++ot) {
+          th[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 0) * 64 + lane];
+          if (PROD >= 2) tl[ks][ot].v = w0[((ks * kOTW + ot) * 2 + 1) * 64 + lane];
+        }
+    }
   };
+  if constexpr (kW0Lds) {
+    const f32x4* w0g = blob + (size_t)wave * K0C * kOTW * 2 * 64;
+    f32x4* w0l = W0s + wave * (K0C * kOTW * 2 * 64);
+#pragma unroll
+    for (int i = 0; i < K0C * kOTW * 2; ++i) w0l[i * 64 + lane] = w0g[i * 64 + lane];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  }
   fetch_w0();
   fetch_queries(blockIdx.x);
   __syncthreads();  // parameter copies visible
