@@ -1,23 +1,9 @@
 #!/bin/bash
+# round-5 evidence: GPU suite, rocprofv3 kernel trace + PMC passes on the driver's command shape, then the driver's bench line
 mkdir -p gpurun_out; exec > gpurun_out/session.log 2>&1
-timeout 600 python -m pytest tests/test_net_parity.py -x -q -m gpu 2>&1 | tail -3
-export RBL_NET_DBG=1
-for v in base new base new; do
-  echo "--- $v"
-  if [ $v = base ]; then export REBEL_HIP_LIB=scratch_alt/librebel_hip_base.so; else unset REBEL_HIP_LIB; fi
-  timeout 120 python scripts/probe_net_shape.py 1 6 270336 40 2 | grep -v amdgpu
-done
-unset REBEL_HIP_LIB
-timeout 120 python scripts/probe_net_shape.py 1 6 270336 40 3 | grep -v amdgpu
-timeout 120 python scripts/probe_net_shape.py 1 4 270336 40 2 | grep -v amdgpu
-export RBL_NET_DBG=0
-for rep in 1 2; do
-for v in base new; do
-  echo "--- bench $v (rep $rep)"
-  if [ $v = base ]; then export REBEL_HIP_LIB=scratch_alt/librebel_hip_base.so; else unset REBEL_HIP_LIB; fi
-  timeout 200 python bench.py --no-extra-legs --no-cpu-baseline --no-configs --steps 4 --warmup 2 | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print({k: d[k] for k in ('value', 'ms_per_step')}, 'net', {k: round(d['roofline'][k], 4) for k in ('frac', 'avg_launch_us', 'ns_per_row')}, 'cfr', {k: round(d['roofline_cfr'][k], 4) for k in ('frac', 'avg_launch_us')}, d['power'])"
-done
-done
+(timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05_gputest.log 2>&1; echo rc=$? >> gpurun_out/r05_gputest.log); tail -3 gpurun_out/r05_gputest.log
+timeout 900 bash scripts/collect_profiles.sh r05
+cp gpurun_out/prof_r05/r05_kernel_stats.csv gpurun_out/prof_r05/r05_kernel_stats_timed_epochs.csv gpurun_out/prof_r05/r05_pmc_traffic.json profiles/ 2>/dev/null
+cp gpurun_out/prof_r05/bench_under_rocprof.json profiles/r05_bench_under_rocprof.json 2>/dev/null
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; echo bench rc=$?
+tail -c 600 gpurun_out/r05_bench.json
