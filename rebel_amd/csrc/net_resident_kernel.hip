@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // more VGPRs made hipcc spill 36-bytes' worth of resident weights at K0C = 3)
   constexpr int kPF = K0C >= 3 ? 1 : (NH == 2 ? RBL_NH2_PF : 2);
 #ifndef RBL_W0_LATE_MIN
-#define RBL_W0_LATE_MIN 3
+#define RBL_W0_LATE_MIN 2  // (round 5: 2 input chunks too -- 19.25 k -> 18.74 k cycles per group at 2 dice x 3 faces; one chunk reads an LDS copy)
 #endif
   constexpr bool kW0Late = K0C >= RBL_W0_LATE_MIN;
   Frag w1h[kRes][kOTW], w1l[kRes][kOTW];
