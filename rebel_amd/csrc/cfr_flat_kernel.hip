@@ -50,6 +50,13 @@ constexpr int kU = 4;  // items whose loads are issued together: a pass is a cha
                        // item (table word -> operands -> store), and with 16 waves per CU only independent work inside a
                        // thread hides them (one item at a time: ~700 cycles per item, 137 k cycles per root lane)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: behind the regret pass and the write-back
+// it made every wave wait for the acknowledgement of global STORES nobody in this launch reads back (regrets, strategy sums and
+// sigma are written once, by the thread that owns the element).  What the passes exchange lives in LDS; the one barrier that
+// does need the global loads to have landed -- the staging barrier, behind the LDS-direct sigma loads -- keeps its vmcnt(0).
+// (Measured, round 5: no difference -- 63.5 k vs 63.1 k ticks per root lane-step; the acknowledgements were never the wait.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // per-node word built at staging: what a pass needs to know about a node's PARENT without a second table round trip
 __device__ __forceinline__ int pk_pr(int w) { return w & 255; }          // reach row of the parent
 __device__ __forceinline__ int pk_pv(int w) { return (w >> 8) & 255; }   // value row of the parent
@@ -311,7 +318,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       }
     }
     RBL_F1();  // terminals
-    __syncthreads();
+    lds_barrier();
     RBL_F1();  // barrier
   }
   RBL_STAMP();  // 2: reach + leaf values
@@ -362,7 +369,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       }
     }
     RBL_F2();  // node values
-    __syncthreads();
+    lds_barrier();
     if (!mine) continue;
     // regrets of the edges into the level below; sigma receives the clamped regrets.  Every global operand of the thread's rows
     // in one round trip (clamped, unconditional: straight-line code)
@@ -394,7 +401,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       }
     }
     RBL_F2();  // regrets
-    __syncthreads();
+    lds_barrier();
     // row sums, sequential over the actions; parked in the (dead) rho_t row.  m / s below is hipcc's f64 division sequence
     // with its denominator-only part (v_rcp_f64 + two Newton steps) done here once per (node, hand); v_div_scale / v_div_fixup
     // are the identity for these operands (1e-80 <= m <= s; scripts/micro/div_shared_rcp.hip checks 3e9 cases against `/`)
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       }
     }
     RBL_F2();  // row sums
-    __syncthreads();
+    lds_barrier();
     if (in_grid) {
       for (int cb = c_lo + my_r; cb < c_hi; cb += kU * R) {
         d2 s[kU], y[kU], m[kU];
@@ -452,7 +459,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
           }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   RBL_STAMP();  // 5: bottom-up
 
@@ -463,7 +470,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     rmean[t * H + tid] = m;
     rho_t[tid] = bel_t;  // root row of the traverser (it served as scratch above)
   }
-  __syncthreads();
+  lds_barrier();
   // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638)
   for (int lev = 1; lev < nlev - 1; ++lev) {
     const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
@@ -486,7 +493,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
           if (dst[u] >= 0) rho_t2[dst[u]] = own ? r[u] * sg[u] : r[u];
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   RBL_STAMP();  // 6: new reach
 
@@ -553,7 +560,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       t_qrec[k] = n | (pr << 9) | (pm << 17) | ((root_player ^ (t_depth[n] & 1)) << 18) | (t_act[n] << 19);
     }
     RBL_F2();  // query sums
-    __syncthreads();
+    lds_barrier();
     // the rows themselves: one item per element, consecutive threads = consecutive floats of the exchange buffer.
     // (x + eps) / s is hipcc's f64 division sequence minus v_div_scale / v_div_fixup, the identity here
     // (1e-80 <= x + eps <= s <= H + 1)
