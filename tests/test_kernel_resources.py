@@ -81,3 +81,19 @@ def test_wave_cfr_kernel_keeps_four_waves_per_simd_for_the_one_die_games():
         assert r["scratch"] == 0, (game, r)
     # 1 die x 6 faces (the headline) and 1 die x 4 faces (config 2): 16 lanes per CU need <= 128 VGPRs
     assert by_h[(1, 6)]["vgprs"] <= 128 and by_h[(1, 4)]["vgprs"] <= 128, by_h
+
+
+def test_wave_cfr_kernel_lds_image_keeps_its_lanes_per_cu():
+    """The one-wavefront CFR kernel is LDS-limited: gfx950 allocates LDS in 1 280-byte granules (measured: the launch time
+    steps exactly there, profiles/r05_cfr_wave_occupancy_sensitivity.txt) and every two lanes per CU are worth ~3 % of the
+    launch.  Root subgame of the headline game: <= 7 granules (18 lanes per CU); 2 dice x 3 faces: <= 10 granules (12)."""
+    import ctypes
+
+    lib = os.path.join(ROOT, "rebel_amd", "librebel_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("librebel_hip.so not built")
+    f = getattr(ctypes.CDLL(lib), "_ZN3rbl18cfr_wave_lds_bytesEiiiiiiii")  # rbl::cfr_wave_lds_bytes(N, NI, H, L, T, faces, lo_d, lo_p)
+    f.restype = ctypes.c_size_t
+    # depth-2 root subgame of a 13-action game: 1 + 12 + 78 nodes, 66 pseudo-leaves, 12 terminals, 13 nodes with children
+    assert f(91, 13, 6, 66, 12, 6, 13, 1) <= 7 * 1280
+    assert f(91, 13, 9, 66, 12, 3, 13, 1) <= 10 * 1280
