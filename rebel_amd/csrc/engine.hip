@@ -228,6 +228,11 @@ void Engine::construct() {
   rows_global_ok_ = !use_lds_ && env_int("RBL_CFR_ROWS", 1) && cfr_rows_global_supported(g_.H, g_.A, g_.dice, g_.faces) &&
                     rows_global_lds_ <= 160 * 1024;
   flat_ok_ = flat_ok_ && rows_global_ok_;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && v > 0) n_cus_ = v;
+    net_grid_env_ = env_int("RBL_NET_GRID", -1);
+  }
   flat_threads_ = std::min(1024, std::max(64, env_int("RBL_CFR_FLAT_THREADS", 1024) / 64 * 64));
   use_order_ = rows_global_ok_ && env_int("RBL_GS_SORT", 1) != 0;
   if (use_order_) d_lane_order_.alloc((size_t)max_lanes_);
@@ -379,6 +384,7 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   d_mlp_blob_.upload(pk.blob, stream_);
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   mlp_ = MlpDev{};
+  mlp_.grid_cap = B_ > 0 ? net_grid_cap(B_) : 0;  // (a weight refresh between epochs keeps the current batch's launch shape)
   mlp_.n_layers = w.n_layers;
   mlp_.n_in = n_in_pack;
   mlp_n_in_true_ = w.n_in;
@@ -610,6 +616,7 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   // lane parts (parts_for; one part from 16384 lanes on, see the constructor): independent lane sets on their
   // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
+  mlp_.grid_cap = net_grid_cap(B);
   part_lanes(B, part_lane_);
   if (use_order_) {  // lanes of each part by tree size, largest first (= shape id ascending), ties by lane index
     std::vector<int> order(B);
@@ -663,6 +670,17 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   pending_trav_ = 0;
 }
 
+// Two small lane parts on two streams: the persistent net kernel of one part owns every CU it runs on, so the other part's CFR
+// step is time-sliced against it.  With three quarters of the CUs for the net kernel the CFR kernel has a place to run beside it
+// (measured, round 5, 4 096 lanes = 2 x 2 048: 1 die x 6 faces 40.5 -> 41.9 M it/s, 1 die x 4 faces 78.8 -> 88.3 M; other caps:
+// 160: 41.7 / 87.3, 208: 40.4 / 77.6; at 2 x 4 096 lanes it costs 1-3 %, and the 2 dice x 6 faces kernels, whose root lanes
+// need whole CUs, lose with any cap: profiles/r05_net_grid_cap_sweep.txt).  RBL_NET_GRID=n overrides (0 = one per CU).
+int Engine::net_grid_cap(int B) const {
+  if (net_grid_env_ >= 0) return net_grid_env_;
+  const int n = parts_for(B);
+  return n >= 2 && wave_ok_ && B / n <= 2048 ? n_cus_ * 3 / 4 : 0;
+}
+
 int Engine::parts_for(int B) const {
   int n = 1;
   while (n < max_parts_ && B >= (n + 1) * split_min_lanes_) ++n;
@@ -692,6 +710,7 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
   num_steps_[0] = num_steps_[1] = 0;
   num_strategies_ = 0;
   n_parts_ = parts_for(B);
+  mlp_.grid_cap = net_grid_cap(B);
   part_lanes(B, part_lane_);
   for (int pt = 0; pt < 4; ++pt) {
     part_bytes_[pt][0] = part_bytes_[pt][1] = 0;

@@ -33,6 +33,9 @@ struct MlpDev {
   // f16 products per multiply (tile 5): 3 = f16x2 split on both operands (f32 parity), 2 = activations rounded to f16,
   // 1 = activations and weights rounded to f16 (half_inference); see net_resident_kernel.hip gemm_resident
   int products = 3;
+  // tile 5: at most this many persistent workgroups (0 = one per CU).  The engine leaves a quarter of the CUs to the OTHER lane
+  // part's CFR kernel when two small parts interleave on two streams (engine.hip: net_grid_cap)
+  int grid_cap = 0;
 };
 
 // Host-side packing: returns one float blob plus the offsets of the members above (in floats).

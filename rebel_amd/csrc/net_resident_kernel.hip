@@ -843,7 +843,8 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   }
   const int cus = dev < 64 ? n_cu[dev] : 256;
   const int n_groups = (int)((rows + kRows - 1) / kRows);
-  const int grid = n_groups < cus ? n_groups : cus;
+  const int cap = m.grid_cap > 0 && m.grid_cap < cus ? m.grid_cap : cus;
+  const int grid = n_groups < cap ? n_groups : cap;
 #define RBL_RES4(K0C_, LN_, NOT_, PROD_, NH_)                                                                                  \
   RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_, NH_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
                    rows, out, n_groups, range)
