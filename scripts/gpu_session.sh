@@ -1,8 +1,6 @@
 #!/bin/bash
+# round-5 evidence refresh: GPU suite + the driver's bench line on the final code
 mkdir -p gpurun_out; exec > gpurun_out/session.log 2>&1
-date
-timeout 1700 python tests/p3_policy_iteration.py --dice 1 --faces 6 --sets 36 --lanes 32 --threads 32 --ref-cache tests/_p3_cache_1d6f --train-device cuda --work /tmp/p3pi > gpurun_out/p3_1d6f_paired.json 2> gpurun_out/p3_1d6f.err
-echo rc=$?
-date
-tail -c 1500 gpurun_out/p3_1d6f_paired.json
-tail -5 gpurun_out/p3_1d6f.err
+(timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05_gputest.log 2>&1; echo rc=$? >> gpurun_out/r05_gputest.log); tail -3 gpurun_out/r05_gputest.log
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err; echo bench rc=$?
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
