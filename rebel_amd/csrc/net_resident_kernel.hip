@@ -286,14 +286,25 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // `s_waitcnt vmcnt(0)`, i.e. behind the store acknowledgements of the group that had just finished, in every group.
   constexpr bool kW0Lds = K0C == 1;
   constexpr int kW0LdsBytes = kW0Lds ? kWaves * K0C * kOTW * 2 * 64 * 16 : 0;
-  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes + kW0LdsBytes];
+  // With one output tile its partials (32 KB) live in the activation image, like those of tiles 1 and 2 always did: nobody reads
+  // X between the first barrier of the last epilogue and the next group's layer-0 epilogue.  The workgroup then needs 128 KB
+  // instead of 148: room for this wave's output-layer fragments in LDS too (kWoLds: the last epilogue has no global load left
+  // and never waits on the vmcnt queue, where the next-but-one group's rows are in flight), and 32 KB of a CU stay free for the
+  // CFR lanes of the other lane part when two small parts interleave.
+  constexpr bool kPinX = NOTV == 1;
+  constexpr int kPBytes = kPinX ? 0 : kWaves * kRT * 64 * 16;
+  constexpr bool kWoLds = K0C == 1 && NOTV == 1;
+  constexpr int kWoLdsBytes = kWoLds ? kWaves * 2 * 64 * 16 : 0;
+  __shared__ __align__(16) unsigned char smem[kImageBytes + kStatBytes + kPBytes + kParamFloats * 4 + kQImageBytes + kW0LdsBytes + kWoLdsBytes];
   f32x4* X = reinterpret_cast<f32x4*>(smem);                 // [ks][hi,lo][row tile][lane] B fragments
   unsigned long long* X8 = reinterpret_cast<unsigned long long*>(smem);
   float* S = reinterpret_cast<float*>(smem + kImageBytes);   // [row][wave] sums of squares
-  f32x4* P = reinterpret_cast<f32x4*>(S + kRows * kWaves);   // [wave][row tile][lane] partial outputs (k slice of a wave)
-  float* prm = reinterpret_cast<float*>(P + kWaves * kRT * 64);  // [layer][bias, gamma, beta'][256], output bias
+  // [wave][row tile][lane] partial outputs of tile 0 (k slice of a wave)
+  f32x4* P = kPinX ? X : reinterpret_cast<f32x4*>(S + kRows * kWaves);
+  float* prm = reinterpret_cast<float*>(smem + kImageBytes + kStatBytes + kPBytes);  // [layer][bias, gamma, beta'][256], output bias
   f32x4* Xq = kEarlyStage ? reinterpret_cast<f32x4*>(prm + kParamFloats) : X;  // B fragments of the query rows (layer 0's input)
-  f32x4* W0s = reinterpret_cast<f32x4*>(smem + kImageBytes + kStatBytes + kWaves * kRT * 64 * 16 + kParamFloats * 4 + kQImageBytes);
+  f32x4* W0s = reinterpret_cast<f32x4*>(smem + kImageBytes + kStatBytes + kPBytes + kParamFloats * 4 + kQImageBytes);
+  f32x4* Wos = reinterpret_cast<f32x4*>(smem + kImageBytes + kStatBytes + kPBytes + kParamFloats * 4 + kQImageBytes + kW0LdsBytes);
   unsigned long long* Xq8 = reinterpret_cast<unsigned long long*>(Xq);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index in an SGPR
   const int lane0 = tid & 63;
@@ -461,8 +472,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #pragma unroll
       for (int t = 0; t < NOT; ++t) {
         const int tt = t < m.out_tiles ? t : 0;
-        woh[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 0) * 64 + lane];
-        if (PROD >= 2) wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
+        if constexpr (kWoLds) {
+          woh[t].v = Wos[(wave * 2 + 0) * 64 + lane];
+          if (PROD >= 2) wol[t].v = Wos[(wave * 2 + 1) * 64 + lane];
+        } else {
+          woh[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 0) * 64 + lane];
+          if (PROD >= 2) wol[t].v = reinterpret_cast<const f32x4*>(m.wo)[((size_t)tt * kKS * 2 + wave * 2 + 1) * 64 + lane];
+        }
       }
     }
     // d = S x (pre-activation): the bias was the accumulators' initial value (init_acc), the 1 / S is part of rs[] below --
@@ -633,6 +649,11 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         }
     }
   };
+  if constexpr (kWoLds) {  // k-step `wave` of output tile 0, hi and lo
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+      Wos[(wave * 2 + part) * 64 + lane] = reinterpret_cast<const f32x4*>(m.wo)[((size_t)wave * 2 + part) * 64 + lane];
+  }
   if constexpr (kW0Lds) {
     const f32x4* w0g = blob + (size_t)wave * K0C * kOTW * 2 * 64;
     f32x4* w0l = W0s + wave * (K0C * kOTW * 2 * 64);
