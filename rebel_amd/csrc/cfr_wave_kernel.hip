@@ -74,7 +74,7 @@ __device__ __forceinline__ double div_by(double num, double s, double y) {  // =
 
 // EHM / LHM / NM: upper bounds of E*H, L*H, N over the engine's shapes (fix the number of staging strides)
 template <int H, int A, int DICE, int FACES, int EHM, int LHM, int NM>
-__global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
+__global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrArgs a) {  // (>= 5 waves per SIMD: the LDS image allows 18 lanes per CU)
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
   constexpr int KS = (EHM + W - 1) / W;
@@ -360,7 +360,9 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       const int c0 = t_cb[n], c1 = t_ce[n];
       if (c0 == c1) continue;
       // the additions stay sequential in ascending action order; the LDS reads of four actions are issued together
-      // (reads past the node's last child land in other rows of the lane's LDS image and are never added)
+      // (reads past the node's last child land in other rows of the lane's LDS image and are never added: a SELECT replaces
+      // them by +0.0 -- adding +0.0 changes no bit, the accumulator starts at +0.0 and a round-to-nearest sum is never -0.0
+      // unless both operands are -- where round 4 had an exec-mask branch per child)
       double x = 0.0;
       const double* ps_ = sig + (c0 - 1) * H + h;
       if (deep) {
@@ -372,18 +374,18 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
             const float v0 = pf_[0], v1 = pf_[H], v2 = pf_[2 * H], v3 = pf_[3 * H];
             const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
             x += (double)v0 * s0;
-            if (c + 1 < cl) x += (double)v1 * s1;
-            if (c + 2 < cl) x += (double)v2 * s2;
-            if (c + 3 < cl) x += (double)v3 * s3;
+            x += c + 1 < cl ? (double)v1 * s1 : 0.0;
+            x += c + 2 < cl ? (double)v2 * s2 : 0.0;
+            x += c + 3 < cl ? (double)v3 * s3 : 0.0;
           }
           if (has_term) x += vterm[(n - lo_p) * H + h] * sig[(c1 - 2) * H + h];
         } else {
           for (int c = c0; c < cl; c += 4, pf_ += 4 * H) {
             const float v0 = pf_[0], v1 = pf_[H], v2 = pf_[2 * H], v3 = pf_[3 * H];
             x += (double)v0;
-            if (c + 1 < cl) x += (double)v1;
-            if (c + 2 < cl) x += (double)v2;
-            if (c + 3 < cl) x += (double)v3;
+            x += c + 1 < cl ? (double)v1 : 0.0;
+            x += c + 2 < cl ? (double)v2 : 0.0;
+            x += c + 3 < cl ? (double)v3 : 0.0;
           }
           if (has_term) x += vterm[(n - lo_p) * H + h];
         }
@@ -394,17 +396,17 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
             const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
             const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
             x += v0 * s0;
-            if (c + 1 < c1) x += v1 * s1;
-            if (c + 2 < c1) x += v2 * s2;
-            if (c + 3 < c1) x += v3 * s3;
+            x += c + 1 < c1 ? v1 * s1 : 0.0;
+            x += c + 2 < c1 ? v2 * s2 : 0.0;
+            x += c + 3 < c1 ? v3 * s3 : 0.0;
           }
         } else {
           for (int c = c0; c < c1; c += 4, pv_ += 4 * H) {
             const double v0 = pv_[0], v1 = pv_[H], v2 = pv_[2 * H], v3 = pv_[3 * H];
             x += v0;
-            if (c + 1 < c1) x += v1;
-            if (c + 2 < c1) x += v2;
-            if (c + 3 < c1) x += v3;
+            x += c + 1 < c1 ? v1 : 0.0;
+            x += c + 2 < c1 ? v2 : 0.0;
+            x += c + 3 < c1 ? v3 : 0.0;
           }
         }
       }
@@ -451,9 +453,9 @@ __global__ void __launch_bounds__(64) cfr_wave_kernel(const CfrArgs a) {
       for (int c = c0; c < c1; c += 4, ps_ += 4 * H) {
         const double s0 = ps_[0], s1 = ps_[H], s2 = ps_[2 * H], s3 = ps_[3 * H];
         s += s0;
-        if (c + 1 < c1) s += s1;
-        if (c + 2 < c1) s += s2;
-        if (c + 3 < c1) s += s3;
+        s += c + 1 < c1 ? s1 : 0.0;
+        s += c + 2 < c1 ? s2 : 0.0;
+        s += c + 3 < c1 ? s3 : 0.0;
       }
       ysum[(n - n0) * H + h] = s;  // (a node with children: its reach-row rank is its node id)
     }

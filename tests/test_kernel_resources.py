@@ -79,8 +79,9 @@ def test_wave_cfr_kernel_keeps_four_waves_per_simd_for_the_one_die_games():
     assert set(by_h) == {(1, 4), (1, 5), (1, 6), (2, 3)}
     for game, r in by_h.items():
         assert r["scratch"] == 0, (game, r)
-    # 1 die x 6 faces (the headline) and 1 die x 4 faces (config 2): 16 lanes per CU need <= 128 VGPRs
-    assert by_h[(1, 6)]["vgprs"] <= 128 and by_h[(1, 4)]["vgprs"] <= 128, by_h
+    # 1 die x 6 faces (the headline): its LDS image allows 18 lanes per CU (round 5), i.e. five waves on some SIMDs: <= 96 VGPRs;
+    # 2 dice x 3 faces: 12 lanes per CU need <= 128
+    assert by_h[(1, 6)]["vgprs"] <= 96 and by_h[(1, 4)]["vgprs"] <= 96 and by_h[(2, 3)]["vgprs"] <= 128, by_h
 
 
 def test_wave_cfr_kernel_lds_image_keeps_its_lanes_per_cu():
