@@ -8,7 +8,8 @@
 //   * sums over the actions of a node run on one thread per (node, hand): the same 12-long sequential chains, but 6x
 //     more of them per instruction (root tree: 78 threads instead of 13);
 //   * regret update, regret matching, normalisation, new reach, strategy sums and the query rows are flat maps over
-//     the edge elements with compile-time H (index arithmetic = a multiply-shift and one table look-up);
+//     the edge elements of the traverser's level; each thread's view of its elements (regret, strategy sum, the LDS offset of
+//     the parent's rows from a per-shape table) is built once and only for the strides that level has (round 5);
 //   * only the per-leaf work that needs a whole reach row at once (scale sum, terminal match histogram) stays
 //     row-per-thread;
 //   * no workgroup barriers: the phases of a lane are ordered by the wave's own in-order LDS pipeline
@@ -19,6 +20,8 @@
 // Arithmetic is operation for operation that of cfr_rows_kernel.hip / cfr_kernels.hip (same operands, same order,
 // -ffp-contract=off, explicit fmas only where those kernels have them), so the bit-exactness contract with the reference
 // (subgame_solving.cc:538-664) is unchanged; tests/test_cfr_parity.py and tests/test_selfplay_parity.py run against it.
+// The LDS image of a lane (8.7 KB at the 1 die x 6 faces root: 18 lanes per CU) keeps pseudo-leaf values as floats -- they are
+// floats by construction -- and the deepest level's terminals as one fp64 row per parent: see "LDS layout" below.
 // Only kModeStep of LDS-resident lanes runs here (RBL_CFR_WAVE=0 switches back to the row kernel).
 #include <algorithm>
 #include <type_traits>
