@@ -5,9 +5,17 @@
 // the GEMM phases run.  A build with the weight loads hoisted out of the k loop ran the hidden-layer GEMM phase in 4.7 K
 // cycles instead of 8.5 K: the phase was bound by weight delivery, not by the matrix pipe.  Two more measurements
 // (scripts/micro/) shaped this kernel:
-//   * on gfx950 the f16 MFMA pipe and the f32 FMA/MUL VALU ops do NOT overlap, not even across waves of one SIMD (times
-//     add to within 5 %), so running GEMM and LayerNorm/GELU phases concurrently in different workgroups buys nothing;
-//     what counts is that each phase runs at its own pipe's rate and that the VALU phase is short;
+//   * what the matrix pipe shares with the VALU (profiles/r03_micro_mfma32_fillers.txt; MI355X_MICROARCH.md "MFMA / VALU
+//     co-issue"): SCALAR f32 VALU ops (v_fma_f32, v_mul, v_min, v_cvt_pkrtz, v_fma_mix) DO overlap f16 MFMAs -- about 5 per
+//     32x32x16 MFMA ride for free (32.0 -> 33.5 cycles, part A), and a SIMD running MFMA waves beside VALU waves takes 520
+//     cycles where the two alone take 544 + 408 (part C).  PACKED f32 ops do not: one v_pk_fma_f32 per MFMA already costs
+//     32 -> 50 cycles, and the GELU below is 7 of them per element pair; v_exp_f32 hides up to 3 per MFMA.  So an
+//     interleaved schedule can hide the split / LayerNorm part of the epilogue behind the GEMM but not the GELU polynomial
+//     (as scalar FMAs it is twice the instructions and lost in tile 5's VALU-only phases: r03_net_pipe_kernel_measurements).
+//     The binding constraint today is neither pipe but the socket: the kernel draws 1 340-1 395 W of the 1 400 W cap, and its
+//     dynamic energy per launch / (cap - idle) is already the measured duration (profiles/r04_net_energy_attribution.txt) --
+//     a denser interleaving is clocked down by the firmware instead of finishing sooner (profiles/r04_power_trace_*.txt).
+//     Hence barrier-separated phases, each at its own pipe's rate, and a short VALU phase;
 //   * v_mfma_f32_16x16x32_f16 honours f16 subnormals, so the low halves of the f16x2 split need no 2^11 pre-scale and
 //     all three partial products can go into ONE f32 accumulator.
 // Hence: a PERSISTENT workgroup per CU (8 waves, 2 per SIMD, 256-VGPR budget), looping over 64-row groups.  Wave w owns
@@ -28,7 +36,7 @@
 // the output features on the host, so only the variance is computed) + GELU 13 (gelu_z below; the 1/sqrt2 going in is
 // folded into the LayerNorm scale and shift, the -sqrt2 coming out into the next layer's weights) + split 4 + bias 1 = 21
 // instructions, against 37 in the tile-3 kernel.  Measured (MI355X, 270k rows): 18.8 k cycles per 64-row group and CU
-// (tile 3: 24.7 k), ~145 us per launch alone; PMC: MFMA busy 33 % + VALU busy 45 % of the time, never together.
+// (tile 3: 24.7 k), ~145 us per launch alone; PMC: MFMA busy 33 % + VALU busy 45 % of the time -- by this kernel's barrier-separated phases, not by a hardware rule (above).
 //
 // Supported shapes: n_hidden == 256 and either n_layers == 2 (one hidden layer, the reference's configuration
 // liars_sp.yaml:28-33; n_in <= 128, n_out <= 64) or n_layers == 3 (Net2's class default, cfvpy/models.py:73; n_in <= 64,

@@ -29,13 +29,13 @@ for lo, hi in ((0, 64), (64, 160), (160, 400)):
     sel = (sizes > lo) & (sizes <= hi)
     if not sel.any():
         continue
-    print(f"trees of {lo} < N <= {hi}: {sel.sum()} lanes, median N {int(np.median(sizes[sel]))}; per-phase 100 MHz ticks (median, p90):")
+    print(f"trees of {lo} < N <= {hi}: {sel.sum()} lanes, median N {int(np.median(sizes[sel]))}; per-phase shader-clock cycles (clock64 = s_memtime) (median, p90):")
     for i, n in enumerate(names):
         if n != "-":
             print(f"  {n:12s} {np.median(dt[sel, i]):8.0f} {np.percentile(dt[sel, i], 90):8.0f}")
     tot = d[:B, 8][sel] - d[:B, 0][sel]
     print("  total        %8.0f %8.0f" % (np.median(tot), np.percentile(tot, 90)))
-print("launch span (max end - min start), 100 MHz ticks:", d[:B, 8].max() - d[:B, 0].min())
+print("launch span (max end - min start), shader-clock cycles:", d[:B, 8].max() - d[:B, 0].min())
 os.environ["RBL_CFR_DBG"] = "0"
 t0 = time.perf_counter()
 e.multistep(40)
