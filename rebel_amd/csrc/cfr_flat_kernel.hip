@@ -67,14 +67,17 @@ template <int H, int A, int DICE, int FACES>
 __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1;
-  typedef const int __attribute__((address_space(4)))* cint_p;
-  typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
-  const int lane = a.lane_order ? ((cint_p)a.lane_order)[a.lane0 + blockIdx.x] : a.lane0 + (int)blockIdx.x;
+  // everything the workgroup must know before its first vector load, in ONE scalar load (cfr_kernels.h: LaneRec, indexed by launch
+  // slot; it was lane_order -> lane -> lane_shape -> shapes[] -> node_off: four dependent round trips -- 20 % of a root lane-step)
+  typedef const LaneRecWords __attribute__((address_space(4)))* crec_p;
+  const LaneRecWords rec = ((crec_p)a.lane_rec)[a.lane0 + blockIdx.x];
+  const int lane = rec[kRecLane];
   const int tid = threadIdx.x, NT = blockDim.x;
-  const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
-  const int N = shc->N, E = N - 1, L = shc->L, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
-  const int NV = N - L, T = shc->T;
-  const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
+  const int N = rec[kRecN], E = N - 1, L = rec[kRecL], NI = rec[kRecNI], nlev = rec[kRecNlev];
+  const int NV = N - L, T = rec[kRecT];
+  const int root_player = rec[kRecRootPlayer], row_off = rec[kRecRowOff];
+  // level offsets of a tree of depth <= 2: {0, 1, lo2, N} (lo2 == N when it has two levels)
+  auto lev_off = [&](int d) { return d <= 0 ? 0 : (d == 1 ? 1 : (d == 2 ? rec[kRecLo2] : N)); };
   const int t = a.trav, opp = 1 - t;
 
   // ---- LDS layout (doubles): rho0, rho1, yrow [NI][H] | val [NV][H] | lsum [L] | qs [4][L] | sig [E][H] | tables
@@ -89,9 +92,10 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   int* t_parent = tb, *t_act = tb + N, *t_cb = tb + 2 * N, *t_ce = tb + 3 * N, *t_depth = tb + 4 * N;
   int* t_pack = tb + 5 * N, *t_lrow = tb + 6 * N, *t_leaf = tb + 7 * N;  // t_leaf [L]: node of net row k
   int* t_term = t_leaf + L;                                              // t_term [T]: the terminals, ascending
-  int* t_qrec = t_term + T;  // [L]: node | parent's reach row << 9 | who acted there << 17 | player to move << 18 | last bid << 19
   // t_mask [FACES][2]: bit h set when hand h shows exactly 1 / exactly 2 of the face (8-byte aligned slot after the ints)
-  unsigned long long* t_mask = reinterpret_cast<unsigned long long*>(tb + ((7 * N + 2 * L + T + 1) & ~1));
+  const int TI = ((7 * N + L + T + 1) & ~1) + 4 * FACES;  // ints of the shape's table blob: everything up to here, in this layout
+  unsigned long long* t_mask = reinterpret_cast<unsigned long long*>(tb + TI - 4 * FACES);
+  int* t_qrec = tb + TI;  // [L]: node | parent's reach row << 9 | who acted there << 17 | player to move << 18 | last bid << 19
 
   const size_t lane_e = (size_t)lane * a.Emax * H;
   double* g_sig = a.sigma + lane_e;
@@ -100,7 +104,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   const float* lvals = a.values + (size_t)row_off * H;
   const double* bel = a.beliefs + (size_t)lane * 2 * H;
   double* rmean = a.root_mean + (size_t)lane * 2 * H;
-  const bool snap_now = a.lane_act_iter && ((cint_p)a.lane_act_iter)[lane] == a.steps_after;
+  const bool snap_now = rec[kRecActIter] == a.steps_after;  // (act_iter < 0: no snapshot; steps_after >= 1)
 
   long long* dbg = a.dbg ? a.dbg + (size_t)lane * 16 : nullptr;
   int dbg_k = 0;
@@ -128,48 +132,30 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     const d2* gs = reinterpret_cast<const d2*>(g_sig);
     d2* ls = reinterpret_cast<d2*>(sig);
     const int EW = E * H / 2;  // H is even
-    // sigma: global -> LDS without a stop in registers (global_load_lds_dwordx4: lane l of a wave lands at base + 16 l,
-    // scripts/micro/global_load_lds.hip): a wave requests its 1 KB chunks back to back and the whole copy is in flight at
-    // once.  (Through registers, 12 pieces per thread at a time, it was four memory round trips: 8 k cycles at the root.)
+    // sigma AND the shape's table blob (tables, pseudo-leaf / value-row map, match masks: flat_tabs, already in this LDS layout):
+    // global -> LDS without a stop in registers (global_load_lds_dwordx4: lane l of a wave lands at base + 16 l,
+    // scripts/micro/global_load_lds.hip): a wave requests its 1 KB chunks back to back and the whole working set is in flight at
+    // once, one round trip behind the record.  (Round 5: eight int tables through registers behind the shape record -- 8 loads per
+    // thread, wait, 8 stores; sigma through registers, 12 pieces per thread at a time, was four memory round trips: 8 k cycles.)
     {
+      typedef int i4 __attribute__((ext_vector_type(4)));
+      const i4* gt = reinterpret_cast<const i4*>(a.flat_tabs + rec[kRecTabOff]);
+      i4* lt = reinterpret_cast<i4*>(tb);
+      const int TW = (TI + 3) / 4;  // 16-byte pieces (the blob is padded; the LDS image has 16 bytes of slack behind t_qrec)
       const int wave = tid >> 6, ln = tid & 63, nw = NT >> 6;
-      const int full = EW / 64;  // 1 KB chunks
-      for (int c = wave; c < full; c += nw)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gs + c * 64 + ln),
-                                         (__attribute__((address_space(3))) void*)(ls + c * 64), 16, 0, 0);
+      const int full = EW / 64, tfull = TW / 64;  // 1 KB chunks
+      for (int c = wave; c < full + tfull; c += nw) {
+        if (c < full)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gs + c * 64 + ln),
+                                           (__attribute__((address_space(3))) void*)(ls + c * 64), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gt + (c - full) * 64 + ln),
+                                           (__attribute__((address_space(3))) void*)(lt + (c - full) * 64), 16, 0, 0);
+      }
       if (tid < EW - full * 64) ls[full * 64 + tid] = gs[full * 64 + tid];
+      const int tt = NT - 1 - tid;  // (the tables' tail on the block's last threads: other waves than sigma's tail where there are several)
+      if (tt < TW - tfull * 64) lt[tfull * 64 + tt] = gt[tfull * 64 + tt];
     }
-    const int* gp = a.parent + node_off;
-    const int* ga = a.act + node_off;
-    const int* gb = a.cb + node_off;
-    const int* ge = a.ce + node_off;
-    const int* gd = a.depth + node_off;
-    const int* gl = a.leaf_row + node_off;
-    const int* gv = a.vrow + node_off;
-    const int* gk = a.pack + node_off;
-    for (int i = tid; i < N; i += NT) {
-      const int lr = gl[i];
-      t_parent[i] = gp[i];
-      t_act[i] = ga[i];
-      t_cb[i] = gb[i];
-      t_ce[i] = ge[i];
-      t_depth[i] = gd[i];
-      t_pack[i] = gk[i];
-      t_lrow[i] = lr >= 0 ? lr : -1 - gv[i];
-      if (lr >= 0) t_leaf[lr] = i;
-    }
-    if (tid < 2 * FACES) {  // H = 36 bytes per face = 9 aligned words, all requested before the first is used
-      static_assert(H % 4 == 0, "match rows are read as words");
-      const int* mrow = reinterpret_cast<const int*>(a.matches + (tid >> 1) * H);
-      int w[H / 4];
-#pragma unroll
-      for (int q = 0; q < H / 4; ++q) w[q] = mrow[q];
-      unsigned long long bits = 0;
-#pragma unroll
-      for (int h = 0; h < H; ++h) bits |= (unsigned long long)(((w[h / 4] >> (8 * (h % 4))) & 255) == (tid & 1) + 1) << h;
-      t_mask[tid] = bits;
-    }
-    for (int i = tid; i < T; i += NT) t_term[i] = (a.terms + shc->term_off)[i];
     if (tid < H) {
       bel_t = bel[t * H + tid];
       rho0[tid] = t == 0 ? bel_t : bel[tid];
@@ -220,7 +206,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       return opp_at_root ? t_parent[n] - 1 : n - 1;
     };
     if (nlev == 3 && in_grid) {  // rows of the depth-1 nodes with children
-      const int n0 = shc->lev_off[1], n1 = shc->lev_off[2];
+      const int n0 = 1, n1 = rec[kRecLo2];
       d2* rho_m2 = root_player == 0 ? rho0_2 : rho1_2;  // the root's mover: times sigma
       d2* rho_n2 = root_player == 0 ? rho1_2 : rho0_2;  // the other player: copied
       for (int nb = n0 + my_r; nb < n1; nb += kU * R) {
@@ -329,8 +315,8 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   // matching (:619-634) and the regret discount (:639-650)
   double* rho_t = t == 0 ? rho0 : rho1;
   for (int lev = nlev - 2; lev >= 0; --lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
-    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
+    const int n0 = lev_off(lev), n1 = lev_off(lev + 1);
+    const int c_lo = n1, c_hi = lev_off(lev + 2);
     const bool mine = (root_player ^ (lev & 1)) == t;
     const bool deepest = lev == nlev - 2;  // the children are the last level
     d2* rho_t2 = reinterpret_cast<d2*>(rho_t);
@@ -473,7 +459,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   lds_barrier();
   // ---------------------------------------------------------------- traverser's reach under the NEW sigma (:636-638)
   for (int lev = 1; lev < nlev - 1; ++lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
+    const int n0 = lev_off(lev), n1 = lev_off(lev + 1);
     const bool own = (root_player ^ ((lev - 1) & 1)) == t;
     d2* rho_t2 = reinterpret_cast<d2*>(rho_t);
     if (in_grid) {
@@ -626,7 +612,9 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
 
 size_t cfr_flat_lds_bytes(int N, int NI, int H, int L, int T, int faces) {
   const size_t d = (size_t)3 * NI * H + (size_t)(N - L) * H + (size_t)((L + 1) & ~1) + (size_t)4 * L + (size_t)(N - 1) * H;  // doubles
-  const size_t b = d * 8 + (((size_t)7 * N + 2 * L + T + 1) & ~(size_t)1) * 4 + (size_t)faces * 16;
+  // ints: the table blob (7 N + L + T, padded to 8 bytes, + the match masks) staged in 16-byte pieces, then t_qrec [L]; 16 bytes of
+  // slack for the last piece
+  const size_t b = d * 8 + ((((size_t)7 * N + L + T + 1) & ~(size_t)1) + (size_t)4 * faces + (size_t)L) * 4 + 16;
   return (b + 15) & ~(size_t)15;
 }
 

@@ -17,6 +17,30 @@ enum CfrMode : int {
   kModeEvaluate = 5,      // compute_ev (subgame_solving.cc:931-973): value of following sigma for the traverser -> br_out
 };
 
+// One 64-byte record per LAUNCH SLOT of the step kernels (cfr_wave_kernel: slot = lane; cfr_flat_kernel: slot = position in the
+// size-sorted lane order of its part): everything a workgroup must know before it can issue its first vector load, fetched with ONE
+// s_load_dwordx16.  It used to be lane_order -> lane -> lane_shape -> shapes[] (+ lane_root_player, lane_row_off, lane_act_iter,
+// wave_tab_off[shape], wave_epv_off[shape]): up to four DEPENDENT scalar round trips in front of the staging loads.
+// Written once per epoch by lane_rec_kernel (launch_lane_rec) from the lane descriptors and the per-shape templates.
+// The level offsets of the depth <= 2 trees these kernels take are {0, 1, lo2, N} (lo2 == N when the tree has two levels).
+struct alignas(64) LaneRec {
+  int lane;         // the lane this slot serves
+  int N, L, T, NI;  // nodes, pseudo-leaves (net rows), terminals, nodes with a reach row
+  int nlev, lo2;    // BFS levels present; first node of level 2
+  int root_player, row_off, act_iter;  // lane descriptors (act_iter < 0: no snapshot)
+  int tab_off;      // cfr_wave_kernel: byte offset of the shape's table blob in wave_tabs; cfr_flat_kernel: int offset in flat_tabs
+  int epv_off;      // cfr_wave_kernel: element offset of the shape's parent-offset table in wave_epv
+  int node_off, term_off, leaf_off;  // ShapeDev's offsets into the per-node int tables (generic consumers)
+  int shape;
+};
+static_assert(sizeof(LaneRec) == 64, "one s_load_dwordx16");
+// the record as the kernels load it: one 16-dword vector from the constant address space (a struct cannot be copied out of it)
+typedef int LaneRecWords __attribute__((ext_vector_type(16)));
+enum LaneRecWord : int {
+  kRecLane = 0, kRecN, kRecL, kRecT, kRecNI, kRecNlev, kRecLo2, kRecRootPlayer, kRecRowOff, kRecActIter, kRecTabOff, kRecEpvOff,
+  kRecNodeOff, kRecTermOff, kRecLeafOff, kRecShape
+};
+
 // Everything the kernel needs; passed by value (fits the kernarg segment).
 struct CfrArgs {
   // ---- static tables (per engine)
@@ -33,10 +57,14 @@ struct CfrArgs {
   const int* vrow;      // node -> rank among the nodes that are not pseudo-leaves, -1 for those (cfr_flat_kernel)
   const int* pack;      // node -> packed rows of its parent (tables.h: ShapeTables::pack; cfr_flat_kernel)
   const int8_t* matches;  // [faces][H]  Game::num_matches (liars_dice.h:83-91)
-  const int8_t* wave_tabs;  // cfr_wave_kernel: per shape parent | act | cb | ce | depth | irank (N bytes each) | leaf nodes (L) |
-  const int* wave_tab_off;  //                  terminal nodes (T) as one 4-byte aligned blob; byte offset of each shape's blob
-  const unsigned short* wave_epv;  // cfr_wave_kernel: per shape, per edge element (c - 1) * H + h: parent(c) * H + h
-  const int* wave_epv_off;         //                  element offset of each shape's table
+  // cfr_wave_kernel: ONE 4-byte aligned blob per shape in exactly the kernel's LDS layout: parent | act | cb | ce (N bytes each) |
+  // leaf nodes (L) | terminal nodes (T) | match table (faces x H); LaneRec::tab_off = its byte offset
+  const int8_t* wave_tabs;
+  const unsigned short* wave_epv;  // cfr_wave_kernel: per shape, per edge element (c - 1) * H + h: parent(c) * H + h (LaneRec::epv_off)
+  // cfr_flat_kernel: ONE 16-byte aligned int blob per shape in exactly the kernel's LDS layout: parent | act | cb | ce | depth | pack |
+  // lrow (N ints each) | leaf nodes (L) | terminals (T) | pad to 8 bytes | match masks (faces x 2 x 8 bytes); LaneRec::tab_off
+  const int* flat_tabs;
+  const LaneRec* lane_rec;  // [max_lanes], by launch slot
   int H, A, Q, faces, dice;
   int Emax, Nmax;         // per-lane strides: Emax*H reals per strategy array
   // ---- per-lane descriptors
@@ -90,6 +118,10 @@ void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out,
                           const long long* range = nullptr);
 
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
+
+// out[slot] = shape_rec[lane_shape[lane]] with the lane's fields filled in, lane = lane_order ? lane_order[slot] : slot
+void launch_lane_rec(const LaneRec* shape_rec, const int* lane_shape, const int* lane_player, const int* lane_row,
+                     const int* lane_act, const int* lane_order, int n, LaneRec* out, hipStream_t stream);
 
 // canonical query rows [rows][Q] = (player, traverser, one-hot last bid [A], reach0 [H], reach1 [H]) <-> split layout:
 // dyn [rows][DS] = (traverser, reach0, reach1, 0...), stat [rows][SS] = (player, one-hot, 0...); `range` as in the net launch

@@ -527,6 +527,30 @@ __global__ void unsplit_queries_kernel(float* __restrict__ canon, int A, int H, 
   canon[i] = k == 0 ? stat[r * SS] : (k == 1 ? dyn[r * DS] : (k < 2 + A ? stat[r * SS + 1 + k - 2] : dyn[r * DS + 1 + k - 2 - A]));
 }
 
+// LaneRec of every launch slot (cfr_kernels.h): the shape's template with the lane's descriptors filled in; one thread per slot,
+// the record written as four 16-byte pieces
+__global__ void __launch_bounds__(256) lane_rec_kernel(const LaneRec* __restrict__ shape_rec, const int* __restrict__ lane_shape,
+                                                       const int* __restrict__ lane_player, const int* __restrict__ lane_row,
+                                                       const int* __restrict__ lane_act, const int* __restrict__ lane_order, int n,
+                                                       LaneRec* __restrict__ out) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const int lane = lane_order ? lane_order[slot] : slot;
+  LaneRec r = shape_rec[lane_shape[lane]];
+  r.lane = lane;
+  r.root_player = lane_player[lane];
+  r.row_off = lane_row[lane];
+  r.act_iter = lane_act ? lane_act[lane] : -1;
+  out[slot] = r;
+}
+
+void launch_lane_rec(const LaneRec* shape_rec, const int* lane_shape, const int* lane_player, const int* lane_row,
+                     const int* lane_act, const int* lane_order, int n, LaneRec* out, hipStream_t stream) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(lane_rec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, shape_rec, lane_shape, lane_player, lane_row,
+                     lane_act, lane_order, n, out);
+}
+
 void launch_split_queries(const float* canon, int A, int H, float* dyn, int DS, float* stat, int SS, int64_t rows,
                           hipStream_t stream, const long long* range) {
   if (rows <= 0) return;

@@ -81,13 +81,16 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   extern __shared__ __align__(16) double lds[];
   constexpr int Q = 2 + A + 2 * H, NB = 2 * DICE + 1, W = 64;
   constexpr int KS = (EHM + W - 1) / W;
-  constexpr int KT = ((5 * NM + 3) / 4 + W - 1) / W;  // dword strides of the byte-table blob (4 N + L + T <= 5 N bytes)
+  constexpr int KT = ((5 * NM + FACES * H + 3) / 4 + W - 1) / W;  // dword strides of the table blob (4 N + L + T <= 5 N bytes, + the match table)
   const int lane = a.lane0 + blockIdx.x, tid = threadIdx.x;
-  typedef const int __attribute__((address_space(4)))* cint_p;
-  typedef const ShapeDev __attribute__((address_space(4)))* cshape_p;
-  const cshape_p shc = (cshape_p)a.shapes + ((cint_p)a.lane_shape)[lane];
-  const int N = shc->N, E = N - 1, L = shc->L, T = shc->T, NI = shc->NI, nlev = shc->nlev, node_off = shc->node_off;
-  const int root_player = ((cint_p)a.lane_root_player)[lane], row_off = ((cint_p)a.lane_row_off)[lane];
+  // everything this lane must know before its first vector load, in ONE scalar load (cfr_kernels.h: LaneRec; it was lane_shape ->
+  // shapes[] -> wave_tab_off / wave_epv_off plus three per-lane arrays: three dependent scalar round trips in front of the staging)
+  typedef const LaneRecWords __attribute__((address_space(4)))* crec_p;
+  const LaneRecWords rec = ((crec_p)a.lane_rec)[lane];
+  const int N = rec[kRecN], E = N - 1, L = rec[kRecL], T = rec[kRecT], NI = rec[kRecNI], nlev = rec[kRecNlev];
+  const int root_player = rec[kRecRootPlayer], row_off = rec[kRecRowOff];
+  // level offsets of a tree of depth <= 2: {0, 1, lo2, N} (lo2 == N when it has two levels)
+  auto lev_off = [&](int d) { return d <= 0 ? 0 : (d == 1 ? 1 : (d == 2 ? rec[kRecLo2] : N)); };
   const int t = a.trav, opp = 1 - t;
   const int EH = E * H, LH = L * H;
 
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   double* g_sum = a.sums + lane_e;
   const double* bel = a.beliefs + (size_t)lane * 2 * H;
   double* rmean = a.root_mean + (size_t)lane * 2 * H;
-  const bool snap_now = a.lane_act_iter && ((cint_p)a.lane_act_iter)[lane] == a.steps_after;
+  const bool snap_now = rec[kRecActIter] == a.steps_after;  // (act_iter < 0: no snapshot; steps_after >= 1)
 
   // ---- LDS layout
   // Node values.  A pseudo-leaf's value is a float by construction ((double)(float)(net row x reach sum), :257-268), and
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   // LAST child of its parent (the liar call is the highest action; the host checks both facts per shape): its fp64 row is
   // kept per PARENT.  Everything above the deepest level keeps an fp64 row per node.  8.7 KB per root lane instead of 10.0 KB at
   // 1 die x 6 faces = 18 lanes per CU instead of 16 (12.7 instead of 14.7 KB at 2 dice x 3 faces: 12 instead of 10).
-  const int lo1 = shc->lev_off[1], lo2 = shc->lev_off[2];
+  const int lo1 = 1, lo2 = rec[kRecLo2];
   const int lo_d = nlev == 3 ? lo2 : lo1, lo_p = nlev == 3 ? lo1 : 0;  // first node of the deepest level / of its parents' level
   const int NP = lo_d - lo_p, ND = N - lo_d;
   double* sig = lds;                  // [E][H]
@@ -193,12 +196,12 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
       load_sig(std::integral_constant<int, KS>{});
     // (the net's output rows go straight into the registers of the thread that will consume them: lv_ below)
     // the lane's tree tables: one byte blob per shape in exactly the LDS layout (parent, act, cb, ce: N bytes each; leaf
-    // nodes: L; terminal nodes: T), copied dword-wise (was: eight int tables, 16 loads per thread, 4 bytes per entry)
-    const int* gt = reinterpret_cast<const int*>(a.wave_tabs + ((cint_p)a.wave_tab_off)[((cint_p)a.lane_shape)[lane]]) + tid;
+    // nodes: L; terminal nodes: T; the game's match table: FACES x H), copied dword-wise (was: eight int tables, 16 loads per
+    // thread, 4 bytes per entry, and a separate load + store for the match table)
+    const int* gt = reinterpret_cast<const int*>(a.wave_tabs + rec[kRecTabOff]) + tid;
     int tw[KT];
 #pragma unroll
     for (int u = 0; u < KT; ++u) tw[u] = gt[u * W];
-    const int8_t tm = a.matches[tid];
     if (tid < H) {
       bel_t = bel[t * H + tid];
       rmean_t = rmean[t * H + tid];
@@ -222,8 +225,6 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
 #pragma unroll
     for (int u = 0; u < KT; ++u) reinterpret_cast<int*>(tb)[tid + u * W] = tw[u];
     static_assert(NM <= 127, "byte tables");
-    static_assert(FACES * H <= W, "match table staged by one store");
-    t_match[tid] = tm;
   }
   wave_sync();
   RBL_STAMP();  // 1: staged
@@ -334,8 +335,8 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   constexpr int KS3 = (KS + 2) / 3, KS23 = (2 * KS + 2) / 3;
   int ch_max = 0;
   for (int lev = nlev - 2; lev >= 0; --lev)
-    if ((root_player ^ (lev & 1)) == t) ch_max = max(ch_max, (shc->lev_off[lev + 2] - shc->lev_off[lev + 1]) * H);
-  const unsigned short* epv = a.wave_epv + ((cint_p)a.wave_epv_off)[((cint_p)a.lane_shape)[lane]];
+    if ((root_player ^ (lev & 1)) == t) ch_max = max(ch_max, (lev_off(lev + 2) - lev_off(lev + 1)) * H);
+  const unsigned short* epv = a.wave_epv + rec[kRecEpvOff];
   auto tail = [&](auto kc) {
   constexpr int K = decltype(kc)::value;
   constexpr int KFULL = K > KS3 ? K - KS3 : 0;  // strides that lie wholly inside the level
@@ -343,8 +344,8 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   int pv[K];
   int lev_kept = -1;
   for (int lev = nlev - 2; lev >= 0; --lev) {
-    const int n0 = shc->lev_off[lev], n1 = shc->lev_off[lev + 1];
-    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
+    const int n0 = lev_off(lev), n1 = lev_off(lev + 1);
+    const int c_lo = n1, c_hi = lev_off(lev + 2);
     const bool mine = (root_player ^ (lev & 1)) == t;
     const int nh = (n1 - n0) * H, ch = (c_hi - c_lo) * H;
     if (mine) {
@@ -497,7 +498,7 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   // the traverser's levels only (contiguous edge ranges), from the per-thread view built in the bottom-up sweep
   for (int lev = 0; lev < nlev - 1; ++lev) {
     if ((root_player ^ (lev & 1)) != t) continue;
-    const int c_lo = shc->lev_off[lev + 1], c_hi = shc->lev_off[lev + 2];
+    const int c_lo = lev_off(lev + 1), c_hi = lev_off(lev + 2);
     const int ch = (c_hi - c_lo) * H, e0 = (c_lo - 1) * H;
     if (lev == lev_kept) {
 #pragma unroll
@@ -598,7 +599,7 @@ size_t cfr_wave_lds_bytes(int N, int NI, int H, int L, int T, int faces, int lo_
   // match table as one 64-byte store behind them: the image must hold whichever reaches further (1 die x 5 faces: the
   // 512-byte table store ends 40 bytes behind the slack of the layout itself)
   const int NM = H == 4 ? 45 : (H == 5 ? 66 : 91);
-  const size_t KT = (size_t)(((5 * NM + 3) / 4 + 63) / 64);
+  const size_t KT = (size_t)(((5 * NM + faces * H + 3) / 4 + 63) / 64);
   b = std::max(b, v + KT * 256);
   b = std::max(b, v + (size_t)(4 * N + L + T) + 64);
   // the sigma staging stores run up to a third of the stride count past the lane's own elements (kernel: "stage"): they must

@@ -188,8 +188,11 @@ class Engine {
   DevBuf<ShapeDev> d_shapes_;
   DevBuf<int> d_parent_, d_act_, d_cb_, d_ce_, d_depth_, d_leaves_, d_terms_, d_irank_, d_leaf_row_, d_vrow_, d_pack_;
   DevBuf<int8_t> d_matches_, d_wave_tabs_;
-  DevBuf<int> d_wave_tab_off_, d_wave_epv_off_;
   DevBuf<unsigned short> d_wave_epv_;
+  DevBuf<int> d_flat_tabs_;
+  DevBuf<LaneRec> d_shape_rec_, d_lane_rec_;  // per-shape templates / per-launch-slot records (cfr_kernels.h: LaneRec)
+  bool wave_tabs_ok_ = false;                 // the game's trees fit cfr_wave_kernel's byte tables and 15-bit offsets
+  void build_lane_records();                  // enqueue lane_rec_kernel on stream_ behind the lane descriptors (and the lane order)
   DevBuf<int> d_shape_epar_;
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
   DevBuf<double> d_beliefs_, d_sigma_, d_regrets_, d_sums_, d_snapshot_, d_root_mean_, d_scratch_;

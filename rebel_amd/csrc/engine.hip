@@ -110,33 +110,83 @@ void Engine::construct() {
   d_leaf_row_.upload(padded(tabs_.leaf_row), stream_);
   d_vrow_.upload(padded(tabs_.vrow), stream_);
   d_pack_.upload(padded(tabs_.pack), stream_);
-  {  // byte blobs of the per-shape tables in the one-wavefront kernel's LDS layout (staged with dword loads)
+  // Per-shape table blobs in the step kernels' LDS layouts + the per-shape LaneRec templates (cfr_kernels.h): a workgroup reads its
+  // 64-byte record and then requests sigma, the net's rows and its tables in ONE burst.
+  {
+    std::vector<LaneRec> srec(tabs_.shapes.size());
+    for (size_t si = 0; si < tabs_.shapes.size(); ++si) {
+      const ShapeDev& s = tabs_.shapes[si];
+      LaneRec& r = srec[si];
+      r = LaneRec{};
+      r.N = s.N;
+      r.L = s.L;
+      r.T = s.T;
+      r.NI = s.NI;
+      r.nlev = s.nlev;
+      r.lo2 = s.lev_off[2];  // (= N for a two-level tree; level 1 always starts at node 1)
+      r.act_iter = -1;
+      r.node_off = s.node_off;
+      r.term_off = s.term_off;
+      r.leaf_off = s.leaf_off;
+      r.shape = (int)si;
+    }
+    // cfr_wave_kernel: byte tables (every entry a node id, an action or -1: needs N <= 127) and the 15-bit parent offsets
+    wave_tabs_ok_ = tabs_.max_N <= 127 && (size_t)tabs_.max_N * g_.H < 32768;
     std::vector<int8_t> blob;
-    std::vector<int> off;
-    for (const ShapeDev& s : tabs_.shapes) {
-      while (blob.size() % 4) blob.push_back(0);
-      off.push_back((int)blob.size());
-      for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce})
-        for (int n = 0; n < s.N; ++n) blob.push_back((int8_t)(*tab)[s.node_off + n]);
-      for (int k = 0; k < s.L; ++k) blob.push_back((int8_t)tabs_.leaves[s.leaf_off + k]);
-      for (int k = 0; k < s.T; ++k) blob.push_back((int8_t)tabs_.terms[s.term_off + k]);
+    std::vector<unsigned short> epv;
+    if (wave_tabs_ok_) {
+      for (size_t si = 0; si < tabs_.shapes.size(); ++si) {
+        const ShapeDev& s = tabs_.shapes[si];
+        while (blob.size() % 4) blob.push_back(0);
+        srec[si].tab_off = (int)blob.size();
+        for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce})
+          for (int n = 0; n < s.N; ++n) blob.push_back((int8_t)(*tab)[s.node_off + n]);
+        for (int k = 0; k < s.L; ++k) blob.push_back((int8_t)tabs_.leaves[s.leaf_off + k]);
+        for (int k = 0; k < s.T; ++k) blob.push_back((int8_t)tabs_.terms[s.term_off + k]);
+        for (int f = 0; f < g_.faces; ++f)  // Game::num_matches (liars_dice.h:83-91), [faces][H]
+          for (int h = 0; h < g_.H; ++h) blob.push_back((int8_t)g_.matches(h, f));
+        // per edge element (c - 1) * H + h: the LDS offset parent(c) * H + h of its parent's value / reach / row-sum row;
+        // bit 15: the child is a terminal (its value lives in its parent's terminal row)
+        srec[si].epv_off = (int)epv.size();
+        for (int c = 1; c < s.N; ++c)
+          for (int h = 0; h < g_.H; ++h)
+            epv.push_back((unsigned short)((tabs_.parent[s.node_off + c] * g_.H + h) | (tabs_.act[s.node_off + c] == g_.liar ? 0x8000 : 0)));
+      }
     }
     blob.resize(blob.size() + kWavePad, 0);
-    d_wave_tabs_.upload(blob, stream_);
-    d_wave_tab_off_.upload(off, stream_);
-    // per edge element (c - 1) * H + h of a shape: the LDS offset parent(c) * H + h (< 2^15) of its parent's value / reach / row-sum row
-    std::vector<unsigned short> epv;
-    std::vector<int> epv_off;
-    for (const ShapeDev& s : tabs_.shapes) {
-      epv_off.push_back((int)epv.size());
-      for (int c = 1; c < s.N; ++c)
-        for (int h = 0; h < g_.H; ++h)  // bit 15: the child is a terminal (its value lives in its parent's terminal row)
-          epv.push_back((unsigned short)((tabs_.parent[s.node_off + c] * g_.H + h) | (tabs_.act[s.node_off + c] == g_.liar ? 0x8000 : 0)));
-    }
     epv.resize(epv.size() + kWavePad, 0);
+    d_wave_tabs_.upload(blob, stream_);
     d_wave_epv_.upload(epv, stream_);
-    d_wave_epv_off_.upload(epv_off, stream_);
-    RBL_HIP_CHECK(hipStreamSynchronize(stream_));  // blob / off go out of scope
+    // cfr_flat_kernel (2 dice x 6 faces): int tables, the pseudo-leaf / value-row map and the match masks, 16-byte aligned per shape
+    std::vector<int> fblob;
+    if (cfr_flat_supported(g_.H, g_.A, g_.dice, g_.faces)) {
+      for (size_t si = 0; si < tabs_.shapes.size(); ++si) {
+        const ShapeDev& s = tabs_.shapes[si];
+        while (fblob.size() % 4) fblob.push_back(0);
+        srec[si].tab_off = (int)fblob.size();
+        for (const std::vector<int>* tab : {&tabs_.parent, &tabs_.act, &tabs_.cb, &tabs_.ce, &tabs_.depth, &tabs_.pack})
+          for (int n = 0; n < s.N; ++n) fblob.push_back((*tab)[s.node_off + n]);
+        for (int n = 0; n < s.N; ++n) {  // lrow: net row of a pseudo-leaf, else -1 - (value row)
+          const int lr = tabs_.leaf_row[s.node_off + n];
+          fblob.push_back(lr >= 0 ? lr : -1 - tabs_.vrow[s.node_off + n]);
+        }
+        for (int k = 0; k < s.L; ++k) fblob.push_back(tabs_.leaves[s.leaf_off + k]);
+        for (int k = 0; k < s.T; ++k) fblob.push_back(tabs_.terms[s.term_off + k]);
+        if (fblob.size() % 2) fblob.push_back(0);
+        for (int f = 0; f < g_.faces; ++f)  // bit h: hand h shows exactly 1 / exactly 2 of the face
+          for (int k = 1; k <= 2; ++k) {
+            unsigned long long bits = 0;
+            for (int h = 0; h < g_.H && h < 64; ++h) bits |= (unsigned long long)(g_.matches(h, f) == k) << h;
+            fblob.push_back((int)(unsigned)(bits & 0xffffffffu));
+            fblob.push_back((int)(unsigned)(bits >> 32));
+          }
+      }
+    }
+    fblob.resize(fblob.size() + kWavePad, 0);
+    d_flat_tabs_.upload(fblob, stream_);
+    d_shape_rec_.upload(srec, stream_);
+    d_lane_rec_.alloc((size_t)max_lanes_);
+    RBL_HIP_CHECK(hipStreamSynchronize(stream_));  // the staging vectors go out of scope
   }
   std::vector<int8_t> m((size_t)g_.faces * g_.H + kWavePad);
   for (int f = 0; f < g_.faces; ++f)
@@ -211,7 +261,7 @@ void Engine::construct() {
       }
     }
     wave_lds_bytes_ += (size_t)std::max(0, env_int("RBL_WAVE_LDS_EXTRA", 0));  // developer aid: occupancy experiments
-    wave_ok_ = use_lds_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 && prefix_ok &&
+    wave_ok_ = use_lds_ && wave_tabs_ok_ && env_int("RBL_CFR_WAVE", 1) && wave_lds_bytes_ <= 64 * 1024 && prefix_ok &&
                cfr_wave_supported(g_.H, g_.A, g_.dice, g_.faces, max_eh, max_lh, nmax_);
   }
   // big games (2 dice x 6 faces): the row kernel with the strategy arrays in place in global memory
@@ -663,6 +713,7 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
       part_rows_block_[part] = rows_block_;
     }
   }
+  build_lane_records();
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
   for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
   num_strategies_ = 0;
@@ -724,10 +775,20 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
     RBL_HIP_CHECK(hipStreamSynchronize(stream_));
     set_segments(seg_shape);
   }
+  build_lane_records();
   RBL_HIP_CHECK(hipEventRecord(ev_ready_, stream_));
   for (int pt = 1; pt < n_parts_; ++pt) RBL_HIP_CHECK(hipStreamWaitEvent(part_stream(pt), ev_ready_, 0));
   launch(kModeInit, 0, 0, 0, 0, 1, 1, 1);
   pending_trav_ = 0;
+}
+
+// The step kernels' per-slot records (cfr_kernels.h: LaneRec) from the epoch's lane descriptors -- uploaded by reset() or written
+// by sp_begin / sp_scan / sp_order, in both cases already enqueued on stream_ -- once per epoch, off the host.
+void Engine::build_lane_records() {
+  if (!wave_ok_ && !flat_ok_) return;
+  launch_lane_rec(d_shape_rec_.p, d_lane_shape_.p, d_lane_player_.p, d_lane_row_.p, d_lane_act_.p,
+                  use_order_ ? d_lane_order_.p : nullptr, B_, d_lane_rec_.p, stream_);
+  RBL_HIP_CHECK(hipGetLastError());
 }
 
 void Engine::split_part_queries(int part, hipStream_t st) {
@@ -826,9 +887,9 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.pack = d_pack_.p;
   a.matches = d_matches_.p;
   a.wave_tabs = d_wave_tabs_.p;
-  a.wave_tab_off = d_wave_tab_off_.p;
   a.wave_epv = d_wave_epv_.p;
-  a.wave_epv_off = d_wave_epv_off_.p;
+  a.flat_tabs = d_flat_tabs_.p;
+  a.lane_rec = d_lane_rec_.p;
   a.H = g_.H;
   a.A = g_.A;
   a.Q = g_.query_size();
