@@ -34,7 +34,7 @@ The JSON line also carries
   per_gpu       (N > 1) every rank's own rate and roofline fractions, and the ranks the RCCL process group saw
   rela_boundary the SAME metric measured the reference's way, through the drop-in boundary (cfvpy/selfplay.py:187-252, 285-293;
                 gen_benchmark.cc:146-153): scripted Net2 in a rela.ModelLocker, rela.ValuePrioritizedReplay(capacity 2 000 000),
-                1 024 x create_cfr_thread (x16 lanes each), Context.start(); rate = delta replay.num_add() / 2 x subgame_iters /
+                1 000 x create_cfr_thread (REBEL_AMD_LANES_PER_GPU spreads the lanes over them), Context.start(); rate = delta replay.num_add() / 2 x subgame_iters /
                 wall-clock between epoch boundaries, WHILE a consumer thread calls replay.sample(512, "cuda:0") in a loop and
                 locker.update_model(net) every 2 s
   cpu_baseline  the UNMODIFIED reference path (oracle/_ref/rela*.so) timed on this box's host cores for >= 30 s per
@@ -144,11 +144,12 @@ def rela_boundary_leg(dice, faces, iters, lanes, device_index, epochs, consumer)
     import rebel_amd.rela as rela
     from rebel_amd.models import Net2
 
-    per = 16  # lanes per create_cfr_thread call: 1 024 calls (selfplay.py:250 seeds rank*1000+i) x 16
-    threads = max(1, lanes // per)
+    # at most 1 000 create_cfr_thread calls per ModelLocker (selfplay.py:250 seeds rank*1000 + i: call #1001 would replay the next
+    # rank's game, and Context.start() refuses it); REBEL_AMD_LANES_PER_GPU spreads the lanes over them (16 384 = 384 x 17 + 616 x 16)
+    threads = max(1, min(1000, lanes))
     dev = f"cuda:{device_index}"
-    prev = os.environ.get("REBEL_AMD_LANES_PER_THREAD")
-    os.environ["REBEL_AMD_LANES_PER_THREAD"] = str(per)
+    prev = os.environ.get("REBEL_AMD_LANES_PER_GPU")
+    os.environ["REBEL_AMD_LANES_PER_GPU"] = str(lanes)
     ctx = None
     try:
         torch.manual_seed(0)
@@ -190,7 +191,7 @@ def rela_boundary_leg(dice, faces, iters, lanes, device_index, epochs, consumer)
         ctx.start()
         if consumer:
             th.start()
-        lanes_run = threads * per
+        lanes_run = lanes
         stamps, last_n, t_begin = [], 0, time.perf_counter()
         skip = 2  # the first epochs carry engine creation and the cold start
         while len(stamps) < skip + epochs + 1:
@@ -212,7 +213,8 @@ def rela_boundary_leg(dice, faces, iters, lanes, device_index, epochs, consumer)
         out = {"value": (n1 - n0) / 2 * iters / (t1 - t0), "unit": "subgame-CFR-iterations/s", "examples_per_s": (n1 - n0) / (t1 - t0),
                "epochs": len(stamps) - 1 - skip, "ms_per_epoch_median": per_epoch[len(per_epoch) // 2],
                "ms_per_epoch_max": per_epoch[-1], "examples_per_epoch": (n1 - n0) // (len(stamps) - 1 - skip),
-               "lanes": lanes_run, "create_cfr_thread_calls": threads, "lanes_per_thread": per,
+               "lanes": lanes_run, "create_cfr_thread_calls": threads,
+               "lanes_per_thread": sorted({lanes // threads, -(-lanes // threads)}),
                "replay": {"capacity": 2000000, "use_priority": False, "prefetch": 8, "storage": replay._storage_device()},
                "consumer": ({"sample_calls_per_s": t_samples0 / max(1e-9, stamps[-1][0] - stamps[0][0]), "batch": 512,
                              "update_model_calls": seen["updates"], "error": seen["error"]} if consumer else None)}
@@ -225,9 +227,9 @@ def rela_boundary_leg(dice, faces, iters, lanes, device_index, epochs, consumer)
                 time.sleep(0.01)
             del ctx
         if prev is None:
-            os.environ.pop("REBEL_AMD_LANES_PER_THREAD", None)
+            os.environ.pop("REBEL_AMD_LANES_PER_GPU", None)
         else:
-            os.environ["REBEL_AMD_LANES_PER_THREAD"] = prev
+            os.environ["REBEL_AMD_LANES_PER_GPU"] = prev
 
 
 def spawn_ranks(n_gpus, share_gpu=False):

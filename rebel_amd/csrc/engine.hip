@@ -434,7 +434,6 @@ void Engine::set_net_mlp(const rbl_mlp_weights& w) {
   d_mlp_blob_.upload(pk.blob, stream_);
   RBL_HIP_CHECK(hipStreamSynchronize(stream_));
   mlp_ = MlpDev{};
-  mlp_.grid_cap = B_ > 0 ? net_grid_cap(B_) : 0;  // (a weight refresh between epochs keeps the current batch's launch shape)
   mlp_.n_layers = w.n_layers;
   mlp_.n_in = n_in_pack;
   mlp_n_in_true_ = w.n_in;
@@ -666,7 +665,6 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   // lane parts (parts_for; one part from 16384 lanes on, see the constructor): independent lane sets on their
   // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
-  mlp_.grid_cap = net_grid_cap(B);
   part_lanes(B, part_lane_);
   if (use_order_) {  // lanes of each part by tree size, largest first (= shape id ascending), ties by lane index
     std::vector<int> order(B);
@@ -761,7 +759,6 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
   num_steps_[0] = num_steps_[1] = 0;
   num_strategies_ = 0;
   n_parts_ = parts_for(B);
-  mlp_.grid_cap = net_grid_cap(B);
   part_lanes(B, part_lane_);
   for (int pt = 0; pt < 4; ++pt) {
     part_bytes_[pt][0] = part_bytes_[pt][1] = 0;
@@ -995,6 +992,10 @@ void Engine::run_net() {
     return;
   }
   const int Q = g_.query_size(), H = g_.H;
+  // the launch shape of the persistent forward follows the BATCH (net_grid_cap), not the net: it is set on a local copy here, under
+  // net_mutex_, so that a weight refresh on another thread (set_net_mlp rebuilds mlp_) never races with it
+  MlpDev mlp = mlp_;
+  mlp.grid_cap = net_grid_cap(B_);
   TimingAbortGuard abort_open_sample_on_unwind{this};
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;
@@ -1005,9 +1006,9 @@ void Engine::run_net() {
     if (timed) time_begin(1, st);
     if (qsplit_ && net_mode_ == NetMode::kMlp) {  // split layout: dynamic rows in, static rows beside them
       if (info_dev_) {
-        launch_mlp_forward(mlp_, d_qdyn_.p, nr, d_values_.p, st, info_dev_->part_row + part);
+        launch_mlp_forward(mlp, d_qdyn_.p, nr, d_values_.p, st, info_dev_->part_row + part);
       } else {
-        MlpDev m2 = mlp_;
+        MlpDev m2 = mlp;
         m2.q_stat = d_qstat_.p + r0 * q_ss_;
         launch_mlp_forward(m2, d_qdyn_.p + r0 * q_ds_, nr, d_values_.p + r0 * H, st, nullptr);
       }

@@ -623,7 +623,11 @@ bool parse_net2_map(const std::map<std::string, torch::Tensor>& sd, MlpHost* out
 int parse_device(const std::string& device) {
   if (device.rfind("cuda", 0) != 0)
     fail("rebel_amd.rela.ModelLocker: device '" + device +
-         "' -- this module generates on an MI355X only (no CPU path); pass 'cuda:N' (cfg: selfplay.cpu_gen_threads=0)");
+         "' -- this module generates on an MI355X only (there is no CPU generation path).  The reference README's first "
+         "command (`python run.py --adhoc --cfg conf/c02_selfplay/liars_sp.yaml ... selfplay.cpu_gen_threads=60`, "
+         "cfvpy/selfplay.py:187-221) builds ModelLocker(models, 'cpu') and fails here; run it as `selfplay.cpu_gen_threads=0 "
+         "selfplay.threads_per_gpu=1000` (one lane per create_cfr_thread call on every GPU but the trainer's; "
+         "REBEL_AMD_LANES_PER_THREAD=16 for 16 000 lanes per GPU) -- pass 'cuda:N'");
   const auto c = device.find(':');
   return c == std::string::npos ? 0 : std::atoi(device.c_str() + c + 1);
 }
@@ -822,21 +826,41 @@ class Context {  // rela/context.h:26-85
   // configuration form ONE worker = one engine on that device + one driver thread.  Pure host logic.
   void plan() {
     if (!workers_.empty()) return;
+    // Lanes per create_cfr_thread call: 1 (the reference's one game per thread), REBEL_AMD_LANES_PER_THREAD = k for k lanes per
+    // call, or REBEL_AMD_LANES_PER_GPU = n for n lanes per ModelLocker spread over its calls (the first n % calls of them take one
+    // more): 1 000 calls -- the most the reference's seed convention rank*1000 + i allows -- then carry e.g. 16 384 lanes as
+    // 384 x 17 + 616 x 16.  Lane j of a call seeded s plays seed s + j * 1000003 (j = 0: the reference's own game).
     const char* lpt = std::getenv("REBEL_AMD_LANES_PER_THREAD");
+    const char* lpg = std::getenv("REBEL_AMD_LANES_PER_GPU");
     const int per = std::max(1, lpt && *lpt ? std::atoi(lpt) : 1);
+    const int per_gpu = lpg && *lpg ? std::atoi(lpg) : 0;
+    std::vector<std::vector<int>> call_seeds;
     for (auto& lane : lanes_) {
-      Worker* w = nullptr;
-      for (auto& c : workers_)
-        if (c->locker == lane->locker && c->replay == lane->replay && same(c->cfg, lane->cfg)) w = c.get();
-      if (!w) {
+      size_t wi = 0;
+      for (; wi < workers_.size(); ++wi) {
+        auto& c = workers_[wi];
+        if (c->locker == lane->locker && c->replay == lane->replay && same(c->cfg, lane->cfg)) break;
+      }
+      if (wi == workers_.size()) {
         workers_.push_back(std::make_unique<Worker>());
-        w = workers_.back().get();
+        Worker* w = workers_.back().get();
         w->locker = lane->locker;
         w->replay = lane->replay;
         w->cfg = lane->cfg;
+        call_seeds.emplace_back();
       }
-      for (int j = 0; j < per; ++j) w->seeds.push_back(lane->seed + j * 1000003);
-      ++w->n_loops;
+      call_seeds[wi].push_back(lane->seed);
+      ++workers_[wi]->n_loops;
+    }
+    for (size_t wi = 0; wi < workers_.size(); ++wi) {
+      const int calls = (int)call_seeds[wi].size();
+      if (per_gpu > 0 && per_gpu < calls)
+        fail("Context: REBEL_AMD_LANES_PER_GPU=" + std::to_string(per_gpu) + " is fewer lanes than the " + std::to_string(calls) +
+             " create_cfr_thread calls that share one ModelLocker");
+      for (int i = 0; i < calls; ++i) {
+        const int k = per_gpu > 0 ? per_gpu / calls + (i < per_gpu % calls ? 1 : 0) : per;
+        for (int j = 0; j < k; ++j) workers_[wi]->seeds.push_back(call_seeds[wi][i] + j * 1000003);
+      }
     }
   }
   // [(device string, device index, create_cfr_thread calls, lane seeds)] per worker -- introspection for tests / logs
@@ -856,12 +880,23 @@ class Context {  // rela/context.h:26-85
     started_ = true;
     workers_.clear();
     plan();
-    for (auto& w : workers_)
-      if (w->n_loops > 1000)  // selfplay.py:250 seeds lanes rank*1000 + i: beyond 1000 per rank they repeat the next rank's
-        std::fprintf(stderr,
-                     "rebel_amd.rela: warning: %d create_cfr_thread calls share one ModelLocker; with the reference's seed "
-                     "convention (rank*1000+i) lanes beyond 1000 duplicate another rank's games -- keep threads_per_gpu <= "
-                     "1000 and scale with REBEL_AMD_LANES_PER_THREAD\n", w->n_loops);
+    // selfplay.py:250 seeds lanes rank*1000 + i: the 1001st call on one ModelLocker would replay the NEXT rank's first game, draw
+    // for draw.  Scaling past 1 000 lanes per GPU is what REBEL_AMD_LANES_PER_THREAD is for (extra lanes are seeded seed +
+    // j*1000003, outside the reference's seed range); with it set the caller has chosen its own seed layout and is trusted.
+    {
+      const char* lpt = std::getenv("REBEL_AMD_LANES_PER_THREAD");
+      const char* lpg = std::getenv("REBEL_AMD_LANES_PER_GPU");
+      for (auto& w : workers_)
+        if (w->n_loops > 1000 && !(lpt && *lpt) && !(lpg && *lpg)) {
+          const int n = w->n_loops;
+          workers_.clear();
+          started_ = false;
+          fail("Context.start: " + std::to_string(n) + " create_cfr_thread calls share one ModelLocker.  With the reference's seed "
+               "convention (cfvpy/selfplay.py:250: rank*1000 + i) call #1001 duplicates another rank's games; keep threads_per_gpu <= "
+               "1000 and scale the lane count with REBEL_AMD_LANES_PER_GPU (e.g. 16384: 1000 calls carry 16-17 lanes each) or "
+               "REBEL_AMD_LANES_PER_THREAD, or set REBEL_AMD_LANES_PER_THREAD=1 to state that your seeds are laid out differently");
+        }
+    }
     for (auto& w : workers_) {  // engines are created here so that configuration errors surface as Python exceptions
       const rbl_params p = to_c(w->cfg.subgame_params);
       w->engine = rbl_engine_create(w->locker->device_index, w->cfg.num_dice, w->cfg.num_faces, &p, (int)w->seeds.size());

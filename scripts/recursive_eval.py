@@ -2,7 +2,7 @@
 """GPU counterpart of the reference's `recursive_eval` tool (csrc/liars_dice/recursive_eval.cc:193-426), on the C ABI.
 
     python scripts/recursive_eval.py --num_dice 1 --num_faces 4 --subgame_iters 1024 --mdp_depth 2 --num_repeats 64 \
-        --net zero|<Net2 state dict .pt/.npz> [--cfr] [--no_linear] [--root_only] [--seed0 0]
+        --net zero|<Net2 state dict .pt/.npz> [--cfr] [--dcfr ALPHA BETA GAMMA] [--no_linear] [--root_only] [--seed0 0]
 
 What it reproduces:
   * "Solving the game for the full tree": the full-tree solver with exploitability printed at iterations 2^k and at the
@@ -17,7 +17,7 @@ What it reproduces:
   * `--print_regret` / `--print_regret_summary` (recursive_eval.cc:28-53): immediate regrets of the list of sampled
     strategies (compute_immediate_regrets, subgame_solving.cc:984-1050 -> rbl_immediate_regrets), CFR runs only, as in
     the reference (:354-357).
-Not reproduced: strategy dumps, oracle-net mode.
+Not reproduced: strategy dumps, oracle-net mode (--repeat_oracle_net, --eval_oracle_values_iters).
 
 `--stream`: the same tool with every full-tree array edge-indexed in HBM (rbl_stream_*, eval_stream.hip) instead of dense
 [N][H][A] host arrays -- the only way to run it at 2 dice x 6 faces (33.5 M nodes: 241 GB dense, 9.7 GB edge-indexed per
@@ -74,7 +74,7 @@ def main_stream(a):
 
     assert a.cfr, "--stream: CFR solvers only"
     d, f = a.num_dice, a.num_faces
-    base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear, use_cfr=True, optimistic=a.optimistic)
+    base = solver_params(a)
     t0 = time.perf_counter()
     s = capi.StreamSolver(d, f, capi.make_params(max_depth=100000, **base), device=a.device)
     print(f"num_dice={d} num_faces={f}")
@@ -134,6 +134,16 @@ def main_stream(a):
     print(f"# stream: full-tree solve {t_full:.1f} s, {max(a.num_repeats, 0)} repeats {t_rep:.1f} s")
 
 
+def solver_params(a):
+    """base_params of the tool (recursive_eval.cc:211-253, :272-273): --dcfr sets the three exponents and takes linear_update off;
+    without --cfr the reference builds FP, which never reads the dcfr fields (subgame_solving.cc:791-800) -- the engine refuses
+    dcfr without use_cfr, so they are passed on only with --cfr."""
+    base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear and a.dcfr is None, use_cfr=a.cfr, optimistic=a.optimistic)
+    if a.dcfr is not None and a.cfr:
+        base.update(dcfr=True, dcfr_alpha=a.dcfr[0], dcfr_beta=a.dcfr[1], dcfr_gamma=a.dcfr[2])
+    return base
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--num_dice", type=int, default=1)
@@ -146,6 +156,8 @@ def main():
     ap.add_argument("--no_linear", action="store_true")
     ap.add_argument("--optimistic", action="store_true")
     ap.add_argument("--cfr", action="store_true")
+    # recursive_eval.cc:248-253: discounted CFR with (alpha, beta, gamma); it switches linear averaging off (:273)
+    ap.add_argument("--dcfr", type=float, nargs=3, metavar=("ALPHA", "BETA", "GAMMA"), default=None)
     ap.add_argument("--print_regret", action="store_true")
     ap.add_argument("--print_regret_summary", action="store_true")
     ap.add_argument("--num_threads", type=int, default=10)  # accepted for command-line compatibility; lanes replace threads
@@ -159,7 +171,7 @@ def main():
     from rebel_amd import capi
 
     d, f = a.num_dice, a.num_faces
-    base = dict(num_iters=a.subgame_iters, linear_update=not a.no_linear, use_cfr=a.cfr, optimistic=a.optimistic)
+    base = solver_params(a)
     tree = capi.unroll_tree(d, f, -1, 0, 1000000)
     print(f"num_dice={d} num_faces={f}")
     print(f"Tree of depth {int(tree[:, 5].max())} has {len(tree)} nodes")

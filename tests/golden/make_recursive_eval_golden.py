@@ -4,6 +4,7 @@ tool oracle/_ref/recursive_eval (csrc/liars_dice/recursive_eval.cc, built by ora
   (b) --net <TorchScript Net2, seed 1234> --mdp_depth 2 --num_repeats 4 --cfr
   (c) --net zero --cfr --print_regret --print_regret_summary   (the regret report of the full-tree section; round 4: made in
       the build container -- it needs no GPU -- and merged into the json: `make_recursive_eval_golden.py --only-regrets`)
+  (d) --net zero --cfr --dcfr 1.5 0 2        (round 6, `--only-dcfr`: discounted CFR, made in the build container like (c))
 on 1 die x 4 faces.  tests/test_eval_parity.py::test_recursive_eval_tool_vs_reference_binary runs scripts/recursive_eval.py
 with the same arguments and compares the XXX / YYY lines (scripts/eval_all.py:100-104 parses them).
 The reference tool loads a TorchScript net on "cuda" first (recursive_eval.cc:316, real_net.cc:130-132), so (b) needs a
@@ -43,6 +44,13 @@ def main():
         golden["zero_regrets"] = run(COMMON + ["--subgame_iters", "64", "--net", "zero", "--print_regret", "--print_regret_summary"])
         json.dump(golden, open(path, "w"), indent=1)
         print("\n".join(golden["zero_regrets"]["stdout"][-10:]))
+        return
+    if "--only-dcfr" in sys.argv:  # round 6: case (d) --dcfr 1.5 0 2 (recursive_eval.cc:248-253), full-tree section, no GPU needed
+        path = os.path.join(ROOT, "tests", "golden", "recursive_eval_1d4f.json")
+        golden = json.load(open(path))
+        golden["zero_dcfr"] = run(COMMON + ["--dcfr", "1.5", "0", "2", "--subgame_iters", "256", "--net", "zero"])
+        json.dump(golden, open(path, "w"), indent=1)
+        print("\n".join(golden["zero_dcfr"]["stdout"][-8:]))
         return
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

@@ -88,7 +88,8 @@ def test_rela_boundary_leg_measures_the_metric_through_the_pybind_surface():
     d = _run(["--lanes", "4096", "--iters", "256", "--rela-epochs", "6"])
     rb = d["rela_boundary"]
     assert rb.get("error") is None and rb["value"] > 0, rb
-    assert rb["lanes"] == 4096 and rb["create_cfr_thread_calls"] == 256 and rb["lanes_per_thread"] == 16
+    # never more than 1 000 create_cfr_thread calls per ModelLocker (the reference's seed convention); the lanes are spread over them
+    assert rb["lanes"] == 4096 and rb["create_cfr_thread_calls"] == 1000 and rb["lanes_per_thread"] == [4, 5]
     assert rb["examples_per_epoch"] == 2 * 4096 and rb["epochs"] == 6
     assert rb["replay"]["storage"] == "cuda:0" and rb["replay"]["capacity"] == 2000000
     assert rb["consumer"]["error"] is None and rb["consumer"]["sample_calls_per_s"] > 0

@@ -278,7 +278,7 @@ def test_recursive_eval_tool_vs_reference_binary():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     golden = json.load(open(os.path.join(root, "tests", "golden", "recursive_eval_1d4f.json")))
-    for case, tol in (("zero", 0.0), ("net", 2e-5)):  # measured on MI355X: max 7e-6
+    for case, tol in (("zero", 0.0), ("zero_dcfr", 0.0), ("net", 2e-5)):  # measured on MI355X: max 7e-6
         g = golden[case]
         out = subprocess.run([sys.executable, os.path.join(root, "scripts", "recursive_eval.py")] + g["args"], cwd=root,
                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
@@ -296,7 +296,7 @@ def test_recursive_eval_tool_vs_reference_binary():
                 else:
                     print(f"[recursive_eval vs reference] {case} {tag} {k}: ours {got[k]} reference {want[k]}")
                     assert abs(float(got[k]) - float(want[k])) <= tol, (case, tag, k, got[k], want[k])
-        if case == "zero":  # the exploitability trace of the full-tree solve, line for line
+        if case in ("zero", "zero_dcfr"):  # the exploitability trace of the full-tree solve, line for line
             want_iter = [l for l in g["stdout"] if l.startswith("Iter=") or l.startswith("Full FP")]
             got_iter = [l for l in lines if l.startswith("Iter=") or l.startswith("Full FP")]
             assert got_iter == want_iter

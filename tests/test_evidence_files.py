@@ -34,8 +34,12 @@ def test_bench_line_arithmetic():
         ids = [c["baseline_config"] for c in d["configs"]]
         assert ids == sorted(ids) and {1, 3, 4} <= set(ids) <= {0, 1, 3, 4}, ids  # round 5 adds configs[0]
         for c in d["configs"]:
-            if "net" in c:
+            # configs 1, 3, 4 carry their kernel fractions and the reference's CPU rate; only config 0 (added in round 5: the
+            # reference's own plumbing case) may lack them
+            if c["baseline_config"] != 0 or "net" in c:
                 assert 0 < c["net"]["frac"] < 1 and 0 < c["cfr"]["frac"] < 1
+            if c["baseline_config"] != 0:
+                assert c["cpu_reference"] is not None
             assert c["value"] > 0 and (c.get("cpu_reference") is None or c["cpu_reference"]["value"] > 0)
 
 

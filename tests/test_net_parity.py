@@ -152,7 +152,7 @@ def test_asymmetric_identity_layout():
 
 
 # ---------------------------------------------------------------------------------------------- half_inference (round 4)
-def _half_case(d, f, rows, seed, out_scale=1.0):
+def _half_case(d, f, rows, seed, out_scale=1.0, n_layers=2):
     """A Net2 whose parameters are f16-representable (what model.half() leaves), query-like inputs, and the outputs of
     (a) float64 arithmetic on those weights, (b) the SAME module as a half torch module on the GPU (the reference's
     half_inference path: cfvpy/selfplay.py:42-43, 211; rela/model_locker.h:85-95)."""
@@ -161,7 +161,7 @@ def _half_case(d, f, rows, seed, out_scale=1.0):
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
 
     torch.manual_seed(seed)
-    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=n_layers).eval()
     with torch.no_grad():
         for prm in net.parameters():
             prm.mul_(1.0 + 0.3 * torch.rand_like(prm))  # LayerNorm weights / biases away from exactly 1 / 0
@@ -185,14 +185,17 @@ def _half_case(d, f, rows, seed, out_scale=1.0):
     return (layers, ln, w_out, b_out), q, ref64, y_half
 
 
-@pytest.mark.parametrize("d,f,rows", [(1, 6, 4000), (1, 4, 1500), (2, 3, 3000), (2, 6, 2500), (1, 6, 65)])
-def test_half_inference_modes_vs_the_half_torch_module(d, f, rows):
+# n_layers = 3 is Net2's CLASS DEFAULT (cfvpy/models.py:73): a half TorchScript module of that depth reaches precision 2 on the
+# NH = 2 instantiations of the resident kernel through rela's apply_mlp (that combination had no parity case)
+@pytest.mark.parametrize("d,f,rows,n_layers", [(1, 6, 4000, 2), (1, 4, 1500, 2), (2, 3, 3000, 2), (2, 6, 2500, 2), (1, 6, 65, 2),
+                                               (1, 6, 4000, 3), (1, 4, 1500, 3), (2, 3, 3000, 3), (1, 6, 65, 3)])
+def test_half_inference_modes_vs_the_half_torch_module(d, f, rows, n_layers):
     """rbl_engine_set_net_precision (VERDICT r3 missing #3).  Against float64 arithmetic on the half model's weights:
     mode 0 keeps the f32-parity bar; mode 1 (activations rounded to f16, two products) and mode 2 (activations and packed
     weights rounded to f16, one product: the reference's half_inference semantics with f32 accumulation / LayerNorm / GELU)
     are each AT LEAST as accurate as the half torch module itself run on this GPU -- the reference's own arithmetic for
     this setting -- in maximum and in mean absolute error."""
-    weights, q, ref64, y_half = _half_case(d, f, rows, seed=3 + rows)
+    weights, q, ref64, y_half = _half_case(d, f, rows, seed=3 + rows, n_layers=n_layers)
     assert np.abs(ref64).max() > 0.05
     err_torch = np.abs(y_half - ref64)
     errs = {}
@@ -201,9 +204,10 @@ def test_half_inference_modes_vs_the_half_torch_module(d, f, rows):
         e.set_net_precision(mode)
         e.set_net_mlp(*weights)
         y = e.net_forward(q)
-        assert e.stats()["net_products"] == 3 - mode
+        st = e.stats()
+        assert st["net_products"] == 3 - mode and st["net_kernel"] == 5  # the register-resident kernel, both depths
         errs[mode] = np.abs(y - ref64)
-    print(f"half_inference {d}dx{f}f: max|err| vs float64 -- torch half module {err_torch.max():.3e} (mean {err_torch.mean():.3e}); "
+    print(f"half_inference {d}dx{f}f n_layers {n_layers}: max|err| vs float64 -- torch half module {err_torch.max():.3e} (mean {err_torch.mean():.3e}); "
           + "; ".join(f"mode {m}: {v.max():.3e} (mean {v.mean():.3e})" for m, v in errs.items()))
     assert errs[0].max() <= ATOL
     for mode in (1, 2):

@@ -158,7 +158,7 @@ def test_real_net_selfplay_at_4096_lanes_sampled_against_oracle(port, lanes, str
     # A 1e-7 difference in one net call is amplified chaotically by CFR; the first game of a lane is mostly
     # root subgames, where 128 iterations keep it tiny, but among hundreds of games a few non-root subgames show it: the claim is
     # on the bulk (all but one game per 64 within 1e-4) and a loose cap on the tail
-    tail = max(1, len(sample) // 64)
+    tail = len(sample) // 64  # (0 for the 14-game sample of the 4 096-lane case: every one of them within 1e-4, as measured -- ADVICE r5)
     assert dqs[min(tail, len(dqs) - 1)] <= 1e-4 and dvs[min(tail, len(dvs) - 1)] <= 1e-4, (dqs[:tail + 1], dvs[:tail + 1])
     assert dqs[0] <= 2e-2 and dvs[0] <= 5e-2, (dqs[0], dvs[0])
 

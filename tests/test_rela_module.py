@@ -184,7 +184,8 @@ def test_model_locker_refuses_cpu_device(ours):
     from rebel_amd.models import Net2
 
     m = torch.jit.script(Net2(num_faces=4, num_dice=1, n_hidden=64, use_layer_norm=True, n_layers=2))
-    with pytest.raises(RuntimeError, match="cuda"):
+    # the message names the reference README command it breaks and the replacement
+    with pytest.raises(RuntimeError, match=r"cpu_gen_threads=60.*cpu_gen_threads=0 selfplay.threads_per_gpu=1000.*cuda"):
         ours.ModelLocker([m], "cpu")
 
 
@@ -284,3 +285,37 @@ def test_context_plans_one_engine_per_model_locker_device(ours, monkeypatch):
     monkeypatch.setenv("REBEL_AMD_LANES_PER_THREAD", "3")  # lanes per create_cfr_thread call, seed stride 1000003
     plan = ctx._plan()
     assert plan[0][2] == 5 and plan[0][3][:4] == [2000, 2000 + 1000003, 2000 + 2 * 1000003, 2001]
+    # ... or lanes per ModelLocker, spread over its calls (the first n % calls take one more): 12 lanes over 5 calls = 3 3 2 2 2
+    monkeypatch.delenv("REBEL_AMD_LANES_PER_THREAD")
+    monkeypatch.setenv("REBEL_AMD_LANES_PER_GPU", "12")
+    plan = ctx._plan()
+    assert plan[0][2] == 5 and len(plan[0][3]) == 12
+    assert plan[0][3] == [2000, 2000 + 1000003, 2000 + 2 * 1000003, 2001, 2001 + 1000003, 2001 + 2 * 1000003,
+                          2002, 2002 + 1000003, 2003, 2003 + 1000003, 2004, 2004 + 1000003]
+    monkeypatch.setenv("REBEL_AMD_LANES_PER_GPU", "3")  # fewer lanes than calls on the first three lockers: refused
+    with pytest.raises(Exception, match="REBEL_AMD_LANES_PER_GPU"):
+        ctx._plan()
+    monkeypatch.delenv("REBEL_AMD_LANES_PER_GPU")
+
+
+def test_call_1001_on_one_locker_is_refused_without_an_explicit_lane_layout(ours, monkeypatch):
+    """cfvpy/selfplay.py:250 seeds generator i of rank r with r*1000 + i: the 1001st create_cfr_thread call on one ModelLocker
+    would replay another rank's game draw for draw.  Context.start() refuses it (round 5: a stderr warning) before any engine
+    is built -- so this needs no GPU -- unless the caller states its lane layout through REBEL_AMD_LANES_PER_GPU / _THREAD."""
+    from rebel_amd.models import Net2
+
+    monkeypatch.delenv("REBEL_AMD_LANES_PER_THREAD", raising=False)
+    monkeypatch.delenv("REBEL_AMD_LANES_PER_GPU", raising=False)
+    m = torch.jit.script(Net2(num_faces=4, num_dice=1, n_hidden=256, use_layer_norm=True, n_layers=2))
+    locker = ours.ModelLocker([m], "cuda:0")
+    replay = ours.ValuePrioritizedReplay(capacity=1024, seed=1, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                         compressed_values=False)
+    cfg = ours.RecursiveSolvingParams()
+    cfg.num_dice, cfg.num_faces = 1, 4
+    cfg.subgame_params.num_iters, cfg.subgame_params.use_cfr = 8, True
+    ctx = ours.Context()
+    for i in range(1001):
+        ctx.push_env_thread(ours.create_cfr_thread(locker, replay, cfg, i))
+    with pytest.raises(Exception, match="1001 create_cfr_thread calls share one ModelLocker"):
+        ctx.start()
+    assert len(ctx._plan()[0][3]) == 1001  # the plan is still inspectable; nothing was started
