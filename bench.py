@@ -373,9 +373,13 @@ def main():
 
     power = {}
 
+    leg_roots = []  # root-subgame lanes of each timed epoch of the LAST run_leg call (the epoch mix of a batch oscillates at first)
+
     def run_leg(game, lanes, warmup, steps, timing_stride, sync_ranks, precision=0, sample_power=False, dump=None):
         """`warmup` untimed + `steps` timed epochs on a fresh engine -> (seconds, units, games, examples, kernel stats)."""
         dice, faces, iters = game
+        n_act = 2 * dice * faces + 1
+        del leg_roots[:]
         params = capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True)
         eng = capi.Engine(dice, faces, params, max_lanes=lanes, device=local_rank)
         eng.set_net_precision(precision)
@@ -398,6 +402,9 @@ def main():
             n, lanes_, q, v = sp.advance(collect=True)  # examples land in host arrays = the replay push hand-off
             units += n
             n_ex += len(lanes_)
+            # lanes whose subgame started at the root state: the one-hot last bid of their example is empty (write_query_to)
+            if getattr(q, "ndim", 0) == 2:
+                leg_roots.append(int((q[0::2, 2:2 + n_act].sum(axis=1) == 0).sum()))
             if dump:
                 kept.append((q, v))
         eng.sync()
@@ -429,6 +436,7 @@ def main():
     dt, units, games, n_examples, st, walk_on_device = run_leg(headline, a.lanes, a.warmup, a.steps, 7, True, sample_power=rank == 0,
                                                                   dump=a.dump_examples)
     net_t, cfr_t, net_tf, cfr_gb = kernel_figures(st)
+    headline_roots = list(leg_roots)
 
     dt_max, units_all, games_all = reduce_job(dist, world if not a.force_dist else max(world, 2), dt, float(units),
                                               float(games)) if use_dist else (dt, float(units), float(games))
@@ -497,15 +505,22 @@ def main():
 
     configs = []
     if world == 1 and not a.no_extra_legs and not a.no_configs and headline == (1, 6, 1024):
-        # the other BASELINE.json configurations on this engine, one GPU; short legs (3 warm-up + 5 timed epochs)
+        # the other BASELINE.json configurations on this engine, one GPU; short legs (3 warm-up + 5 timed epochs) -- except 2 dice x 6
+        # faces, whose root / small-tree mix oscillates for the first epochs of a batch (all lanes start at the root: 2 048, 105,
+        # 1 673, 419, 1 431 ... roots, scripts/probe_2d6f_mix.py) and decides its rate: 8 warm-up + 8 timed epochs there, and every
+        # leg prints its per-epoch root count so that two runs can be compared
         for idx, d_, f_, it_, ln_ in OTHER_CONFIGS:
-            cw, cs = min(3, max(1, a.warmup)), min(5, max(2, a.steps))
+            cw, cs = (8, 8) if (d_, f_) == (2, 6) else (min(3, max(1, a.warmup)), min(5, max(2, a.steps)))
+            if a.steps < 3:  # test-sized runs stay short
+                cw, cs = min(cw, 3), min(cs, 2)
             cdt, cunits, cgames, _, cst, _ = run_leg((d_, f_, it_), ln_, cw, cs, 7, False)
+            croots = list(leg_roots)
             cnet, ccfr = roofline_blocks((d_, f_, it_), cst, int(cst["n_streams"]))
             keep = ("kernel", "achieved", "unit", "frac", "avg_launch_us", "timed_launches")
             configs.append({"baseline_config": idx, "workload": f"{d_}dx{f_}f self-play, {ln_} lanes, subgame_iters={it_}, depth 2",
                             "value": cunits / cdt, "unit": "subgame-CFR-iterations/s", "ms_per_step": cdt / cs * 1e3,
                             "steps": cs, "warmup": cw, "games_per_s": cgames / cdt, "streams": int(cst["n_streams"]),
+                            "roots_per_epoch": croots,
                             "net": {k: cnet[k] for k in keep + ("rows_per_launch", "ns_per_row")},
                             "cfr": {k: ccfr[k] for k in keep + ("algorithmic_bytes_per_launch",)}})
 
@@ -541,31 +556,52 @@ def main():
             "roofline_cfr": rl_cfr,
             "streams": streams,
             "selfplay_walk": "device kernels" if walk_on_device == 1 else "host",
+            "roots_per_epoch": headline_roots,  # rank 0's lanes in their root subgame, per timed epoch (identical work: DESIGN 7)
         }
         for key, kern in (("roofline", ("mlp_resident_kernel",)), ("roofline_cfr", ("cfr_wave_kernel", "cfr_rows_kernel"))):
-            # the committed PMC passes were taken on the headline configuration: other games report traffic = null
+            # Everything in this object is READ FROM FILES COMMITTED UNDER profiles/ (an earlier rocprofv3 session of this same
+            # command on another box of the pool), never measured by this run: PMC counter passes serialise the kernels and cannot
+            # ride in a timed run.  It is kept apart from the live figures (achieved / frac / avg_launch_us above are this run's HIP
+            # events); `traffic` beside them stays null in the live line.
+            fcp = {}
+            # the committed PMC passes were taken on the headline configuration: other games carry none
             tr = pmc_traffic(kern) if headline == (1, 6, 1024) else None
-            if tr:  # PMC passes are a separate (committed) run of this command; scale by the lanes they were taken at
+            if tr:  # scaled by the lanes the passes were taken at
                 scale = (a.lanes / tr["lanes_profiled"]) if tr.get("lanes_profiled") else 1.0
-                out[key]["traffic"] = tr["bytes"] * scale
-                out[key]["traffic_detail"] = tr
-                out[key]["traffic_measured"] = ("NOT in this run: counter passes serialise the kernels, so they are a separate, "
-                                                "committed rocprofv3 --pmc run of this same command (source in traffic_detail)")
+                fcp["traffic"] = tr["bytes"] * scale
+                fcp["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, gfx950 corrections)"
+                fcp["traffic_detail"] = tr
+                work = out[key].get("algorithmic_bytes_per_launch")
+                if work:
+                    fcp["traffic_over_algorithmic"] = fcp["traffic"] / work
             rp = rocprof_timed_epochs(kern, (a.steps, a.warmup)) if headline == (1, 6, 1024) else None
             if rp and rp.get("lanes_profiled") == a.lanes:
-                # the same launches (same seeds, lanes, warm-up, timed epochs) as seen by rocprofv3 in the committed profile: the
-                # algorithmic work per launch is identical, so frac follows from that run's duration
+                # the same launches (same seeds, lanes, warm-up, timed epochs) as seen by rocprofv3 --kernel-trace in the committed
+                # profile: the algorithmic work per launch is identical, so a frac follows from that run's duration
                 work = out[key]["algorithmic_flops_per_launch"] / 1e12 if key == "roofline" else \
                     out[key]["algorithmic_bytes_per_launch"] / 1e9
                 rp["achieved"] = work / (rp["avg_launch_us"] * 1e-6)
                 rp["frac"] = rp["achieved"] / out[key]["peak"]
-                out[key]["rocprof"] = rp
+                fcp["rocprof"] = rp
+            if fcp:
+                fcp["note"] = "NOT measured in this run: read from the committed profiles named in `source`"
+                out[key]["from_committed_profile"] = fcp
         if power.get("headline"):
             # the dominant kernel is socket-power-bound (84 % of the step at ~1.39 kW of a 1.4 kW cap): see DESIGN.md 3.4
             out["power"] = power["headline"]
         if per_rank:
             if a.share_gpu:
                 out["share_gpu"] = "TEST MODE: every rank ran on GPU 0 (gloo bookkeeping); not a scaling measurement"
+            # north_star: "1/2/4/8-GPU throughput reported as absolute numbers and as fraction of HBM roofline" -- the job's CFR sweep
+            # against N x 8 TB/s and its net forward against N x the f16 MFMA peak (sums of the ranks' live kernel figures)
+            n_r = len(per_rank)
+            out["job"] = {"n_gpus": n_r, "value": out["value"], "value_per_gpu_mean": sum(r[2] for r in per_rank) / n_r,
+                          "value_per_gpu_min": min(r[2] for r in per_rank), "value_per_gpu_max": max(r[2] for r in per_rank),
+                          "cfr_gbps_sum": sum(r[6] for r in per_rank), "hbm_peak_gbps_sum": HBM_PEAK_GBPS * n_r,
+                          "cfr_frac_of_n_x_hbm_roofline": sum(r[6] for r in per_rank) / (HBM_PEAK_GBPS * n_r),
+                          "net_tflops_sum": sum(r[4] for r in per_rank) * MFMA_F16_PEAK_TFLOPS,
+                          "net_frac_of_n_x_mfma_peak": sum(r[4] for r in per_rank) / n_r,
+                          "slowest_rank_seconds": max(r[3] for r in per_rank), "fastest_rank_seconds": min(r[3] for r in per_rank)}
             out["per_gpu"] = {"ranks_seen_by_rccl": dist.get_world_size(), "backend": dist.get_backend(),
                               "ranks": [{"rank": int(r[0]), "gpu": int(r[1]), "value": r[2], "seconds": r[3], "net_frac_mfma": r[4],
                                          "cfr_frac_hbm": r[5], "cfr_gbps": r[6], "net_launch_us": r[7], "cfr_launch_us": r[8]}

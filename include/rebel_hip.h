@@ -245,6 +245,13 @@ int rbl_selfplay_device_examples(rbl_selfplay* sp, const float** queries_dev, co
  * order per round, produced by the GPU.  tests/ compares them with the host library draw for draw. */
 int rbl_selftest_device_rng(int device, int32_t seed, int rounds, int hi, const double* w, int nw, double* out);
 int64_t rbl_selfplay_games_finished(rbl_selfplay* sp);
+/* Root de-duplication (opt-in extra, REBEL_AMD_ROOT_DEDUP=1 in the environment when the lanes are created; default off; no
+ * counterpart in the reference).  RlRunner::step resets a finished game to the root state with uniform beliefs
+ * (recursive_solving.cc:160-163) and CFR::step draws nothing, so every lane that is in its root subgame in an epoch computes the
+ * same num_iters iterations.  With the option on, one lane per epoch solves the root subgame and the other root lanes sample from
+ * its strategy at THEIR act_iteration: trajectories and training examples stay bit-identical per seed, rbl_selfplay_advance then
+ * returns the iterations actually EXECUTED, and this call returns the lane-epochs served that way so far (0 when off). */
+int64_t rbl_selfplay_root_dedup_served(rbl_selfplay* sp);
 /* per-lane public state for inspection: last_bid, player_id (liars_dice.h:35-44) */
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id);
 

@@ -29,6 +29,7 @@ SYMBOLS = [
     "rbl_solver_num_lanes", "rbl_solver_tree_size", "rbl_solver_total_rows", "rbl_solver_get",
     "rbl_solver_get_snapshot", "rbl_solver_set_strategy", "rbl_solver_best_response", "rbl_exploitability2", "rbl_ev2", "rbl_immediate_regrets", "rbl_solver_evaluate", "rbl_strategy_recursive", "rbl_strategy_recursive_sampled", "rbl_exploitability_recursive", "rbl_exploitability_recursive_deal", "rbl_exploitability_top_nodes", "rbl_exploitability_combine", "rbl_stream_create", "rbl_stream_destroy", "rbl_stream_num_nodes", "rbl_stream_step", "rbl_stream_exploitability", "rbl_stream_get", "rbl_stream_last_error", "rbl_stream_sampled_reset", "rbl_stream_sampled_add", "rbl_stream_sampled_add_root_only", "rbl_stream_regrets_reset", "rbl_stream_regrets_add", "rbl_stream_regrets_report", "rbl_stream_sampled_eval", "rbl_solver_hand_values", "rbl_solver_examples", "rbl_solver_get_queries", "rbl_solver_debug_stamps", "rbl_net_debug_stamps",
     "rbl_selfplay_create", "rbl_selfplay_destroy", "rbl_selfplay_advance", "rbl_selfplay_games_finished",
+    "rbl_selfplay_root_dedup_served",
     "rbl_selfplay_state", "rbl_selfplay_on_device", "rbl_selfplay_device_examples", "rbl_selftest_device_rng",
     "rbl_engine_timing", "rbl_engine_stats",
 ]
@@ -153,6 +154,7 @@ def lib():
         "rbl_selfplay_destroy": (None, [vp]),
         "rbl_selfplay_advance": (C.c_int64, [vp, EXAMPLE_FN, vp]),
         "rbl_selfplay_games_finished": (C.c_int64, [vp]),
+        "rbl_selfplay_root_dedup_served": (C.c_int64, [vp]),
         "rbl_selfplay_state": (C.c_int, [vp, C.c_int, i32p, i32p]),
         "rbl_selfplay_on_device": (C.c_int, [vp]),
         "rbl_selfplay_device_examples": (C.c_int, [vp, C.POINTER(fp), C.POINTER(fp)]),
@@ -551,6 +553,10 @@ class SelfPlay:
 
     def games_finished(self):
         return self.e.L.rbl_selfplay_games_finished(self.h)
+
+    def root_dedup_served(self):
+        """lane-epochs served by the epoch's representative root solve so far (REBEL_AMD_ROOT_DEDUP=1; 0 when off)"""
+        return self.e.L.rbl_selfplay_root_dedup_served(self.h)
 
     def on_device(self):
         """1: the sampling walk runs as HIP kernels; 0: on the host (callback net / RBL_SELFPLAY_HOST=1).  Decides on first use."""

@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   // slot; it was lane_order -> lane -> lane_shape -> shapes[] -> node_off: four dependent round trips -- 20 % of a root lane-step)
   typedef const LaneRecWords __attribute__((address_space(4)))* crec_p;
   const LaneRecWords rec = ((crec_p)a.lane_rec)[a.lane0 + blockIdx.x];
+  if (rec[kRecFlags] & kRecSkip) return;  // root de-duplication: this root lane is served by the epoch's representative
   const int lane = rec[kRecLane];
   const int tid = threadIdx.x, NT = blockDim.x;
   const int N = rec[kRecN], E = N - 1, L = rec[kRecL], NI = rec[kRecNI], nlev = rec[kRecNlev];
@@ -486,6 +487,9 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   // ---------------------------------------------------------------- sum_strategies (:651-657) + write back what changed
   {
     d2* snap_2 = reinterpret_cast<d2*>(a.snapshot + lane_e);
+    // (root de-duplication: the representative also keeps sigma after EVERY iteration for the root lanes it serves)
+    const bool rep = (rec[kRecFlags] & kRecRep) != 0;
+    d2* snap_all_2 = reinterpret_cast<d2*>(a.snap_all + (size_t)(rep ? a.steps_after : 0) * a.Emax * H);
     d2* gsum_2 = reinterpret_cast<d2*>(g_sum);
     d2* gsig_2 = reinterpret_cast<d2*>(g_sig);
     const d2* rho_t2 = reinterpret_cast<const d2*>(rho_t);
@@ -509,6 +513,7 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
               gsig_2[e] = s;
             }
             if (snap_now) snap_2[e] = s;
+            if (rep) snap_all_2[e] = s;
           }
       }
     }

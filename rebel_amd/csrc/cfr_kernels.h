@@ -30,15 +30,18 @@ struct alignas(64) LaneRec {
   int root_player, row_off, act_iter;  // lane descriptors (act_iter < 0: no snapshot)
   int tab_off;      // cfr_wave_kernel: byte offset of the shape's table blob in wave_tabs; cfr_flat_kernel: int offset in flat_tabs
   int epv_off;      // cfr_wave_kernel: element offset of the shape's parent-offset table in wave_epv
-  int node_off, term_off, leaf_off;  // ShapeDev's offsets into the per-node int tables (generic consumers)
+  int node_off, term_off;  // ShapeDev's offsets into the per-node int tables (generic consumers)
+  int flags;        // kRecSkip: no work for this slot (root de-duplication: a root lane served by the epoch's representative);
+                    // kRecRep: the representative -- store sigma after EVERY iteration into CfrArgs::snap_all[steps_after]
   int shape;
 };
+constexpr int kRecSkip = 1, kRecRep = 2;
 static_assert(sizeof(LaneRec) == 64, "one s_load_dwordx16");
 // the record as the kernels load it: one 16-dword vector from the constant address space (a struct cannot be copied out of it)
 typedef int LaneRecWords __attribute__((ext_vector_type(16)));
 enum LaneRecWord : int {
   kRecLane = 0, kRecN, kRecL, kRecT, kRecNI, kRecNlev, kRecLo2, kRecRootPlayer, kRecRowOff, kRecActIter, kRecTabOff, kRecEpvOff,
-  kRecNodeOff, kRecTermOff, kRecLeafOff, kRecShape
+  kRecNodeOff, kRecTermOff, kRecFlags, kRecShape
 };
 
 // Everything the kernel needs; passed by value (fits the kernarg segment).
@@ -78,6 +81,10 @@ struct CfrArgs {
   double* regrets;
   double* sums;      // sum_strategies
   double* snapshot;  // sigma at act_iteration
+  // root de-duplication (selfplay_kernels.h; null / unused when off): lane_skip[lane] 0 = normal, 1 = skipped, 2 = representative;
+  // the representative also stores sigma after every iteration k into snap_all[k][Emax*H] (k = 0: the uniform start)
+  const int* lane_skip;
+  double* snap_all;
   double* root_mean; // [B][2][H] root_values_means
   // ---- net exchange
   float* queries;       // [rows][Q]
@@ -120,8 +127,9 @@ void launch_synthetic_net(const float* queries, int64_t rows, int Q, float* out,
 void launch_cfr(const CfrArgs& a, int B, int block, size_t lds_bytes, hipStream_t stream);
 
 // out[slot] = shape_rec[lane_shape[lane]] with the lane's fields filled in, lane = lane_order ? lane_order[slot] : slot
+// (lane_skip: root de-duplication flags per lane, or null -> LaneRec::flags)
 void launch_lane_rec(const LaneRec* shape_rec, const int* lane_shape, const int* lane_player, const int* lane_row,
-                     const int* lane_act, const int* lane_order, int n, LaneRec* out, hipStream_t stream);
+                     const int* lane_act, const int* lane_order, const int* lane_skip, int n, LaneRec* out, hipStream_t stream);
 
 // canonical query rows [rows][Q] = (player, traverser, one-hot last bid [A], reach0 [H], reach1 [H]) <-> split layout:
 // dyn [rows][DS] = (traverser, reach0, reach1, 0...), stat [rows][SS] = (player, one-hot, 0...); `range` as in the net launch

@@ -84,6 +84,9 @@ template <int HT, int AT, bool LDS>
 __global__ void cfr_step_kernel(const CfrArgs a) {
   extern __shared__ __align__(16) double lds[];
   const int lane = a.lane0 + blockIdx.x;
+  // root de-duplication (selfplay_kernels.h): a served root lane has no rows and takes no part in any launch
+  const int dedup_role = a.lane_skip ? a.lane_skip[lane] : 0;
+  if (dedup_role == 1) return;
   const int H = HT > 0 ? HT : a.H, A = AT > 0 ? AT : a.A, Q = HT > 0 ? 2 + AT + 2 * HT : a.Q;
   const ShapeDev& sh = a.shapes[a.lane_shape[lane]];
   LaneView v;  // the tables the phases read: LDS copies when LDS, the global tables otherwise
@@ -214,6 +217,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
         const double r = (mover == 0 ? rho0 : rho1)[p * H + h];
         g_sum[i] = sig[i] * r;
         if (snap_now) snap[i] = sig[i];
+        if (dedup_role == 2) a.snap_all[i] = sig[i];  // sigma "after iteration 0": the uniform start
       }
   }
 
@@ -427,6 +431,7 @@ __global__ void cfr_step_kernel(const CfrArgs a) {
             g_reg[i] = reg[i];
           }
           if (snap_now) snap[i] = sig[i];
+          if (dedup_role == 2) a.snap_all[(size_t)a.steps_after * a.Emax * H + i] = sig[i];
         }
     }
     }  // CFR (not FP)
@@ -531,8 +536,8 @@ __global__ void unsplit_queries_kernel(float* __restrict__ canon, int A, int H, 
 // the record written as four 16-byte pieces
 __global__ void __launch_bounds__(256) lane_rec_kernel(const LaneRec* __restrict__ shape_rec, const int* __restrict__ lane_shape,
                                                        const int* __restrict__ lane_player, const int* __restrict__ lane_row,
-                                                       const int* __restrict__ lane_act, const int* __restrict__ lane_order, int n,
-                                                       LaneRec* __restrict__ out) {
+                                                       const int* __restrict__ lane_act, const int* __restrict__ lane_order,
+                                                       const int* __restrict__ lane_skip, int n, LaneRec* __restrict__ out) {
   const int slot = blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= n) return;
   const int lane = lane_order ? lane_order[slot] : slot;
@@ -541,14 +546,16 @@ __global__ void __launch_bounds__(256) lane_rec_kernel(const LaneRec* __restrict
   r.root_player = lane_player[lane];
   r.row_off = lane_row[lane];
   r.act_iter = lane_act ? lane_act[lane] : -1;
+  const int sk = lane_skip ? lane_skip[lane] : 0;
+  r.flags = sk == 1 ? kRecSkip : (sk == 2 ? kRecRep : 0);
   out[slot] = r;
 }
 
 void launch_lane_rec(const LaneRec* shape_rec, const int* lane_shape, const int* lane_player, const int* lane_row,
-                     const int* lane_act, const int* lane_order, int n, LaneRec* out, hipStream_t stream) {
+                     const int* lane_act, const int* lane_order, const int* lane_skip, int n, LaneRec* out, hipStream_t stream) {
   if (n <= 0) return;
   hipLaunchKernelGGL(lane_rec_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, shape_rec, lane_shape, lane_player, lane_row,
-                     lane_act, lane_order, n, out);
+                     lane_act, lane_order, lane_skip, n, out);
 }
 
 void launch_split_queries(const float* canon, int A, int H, float* dyn, int DS, float* stat, int SS, int64_t rows,

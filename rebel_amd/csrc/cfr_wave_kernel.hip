@@ -87,6 +87,7 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
   // shapes[] -> wave_tab_off / wave_epv_off plus three per-lane arrays: three dependent scalar round trips in front of the staging)
   typedef const LaneRecWords __attribute__((address_space(4)))* crec_p;
   const LaneRecWords rec = ((crec_p)a.lane_rec)[lane];
+  if (rec[kRecFlags] & kRecSkip) return;  // root de-duplication: this root lane is served by the epoch's representative
   const int N = rec[kRecN], E = N - 1, L = rec[kRecL], T = rec[kRecT], NI = rec[kRecNI], nlev = rec[kRecNlev];
   const int root_player = rec[kRecRootPlayer], row_off = rec[kRecRowOff];
   // level offsets of a tree of depth <= 2: {0, 1, lo2, N} (lo2 == N when it has two levels)
@@ -534,6 +535,10 @@ __global__ void __launch_bounds__(64, H == 9 ? 4 : 5) cfr_wave_kernel(const CfrA
     tail(std::integral_constant<int, KS>{});
   if (snap_now) {
     double* snap = a.snapshot + lane_e;
+    for (int i = tid; i < EH; i += W) snap[i] = sig[i];
+  }
+  if (rec[kRecFlags] & kRecRep) {  // the representative keeps sigma after EVERY iteration for the root lanes it serves
+    double* snap = a.snap_all + (size_t)a.steps_after * a.Emax * H;
     for (int i = tid; i < EH; i += W) snap[i] = sig[i];
   }
   RBL_STAMP();  // 7: write-back

@@ -132,6 +132,12 @@ class Engine {
   void part_lanes(int B, int* part_lane /*[kSpMaxParts+1]*/) const;
   void begin_epoch_device(int B, const SpEpochInfo* info_dev);   // descriptors already enqueued on stream(); solver init
   void join_streams();                                           // stream() waits for the other parts' streams
+  // root de-duplication of device-resident epochs (selfplay_kernels.h): allocates the per-lane flags and the representative's
+  // sigma-per-iteration slab; false (nothing changed) when this engine's step kernels cannot skip lanes
+  bool enable_root_dedup();
+  bool root_dedup() const { return root_dedup_; }
+  int* lane_skip_dev() const { return root_dedup_ ? d_lane_skip_.p : nullptr; }
+  const double* snap_all_dev() const { return root_dedup_ ? d_snap_all_.p : nullptr; }
   void end_epoch_device(const SpEpochInfo& info);                // accounting of the timed launches; rows of the epoch
 
   // bulk read-back used by SelfPlay (edge-indexed, stride Emax*H per lane)
@@ -192,6 +198,9 @@ class Engine {
   DevBuf<int> d_flat_tabs_;
   DevBuf<LaneRec> d_shape_rec_, d_lane_rec_;  // per-shape templates / per-launch-slot records (cfr_kernels.h: LaneRec)
   bool wave_tabs_ok_ = false;                 // the game's trees fit cfr_wave_kernel's byte tables and 15-bit offsets
+  bool root_dedup_ = false;
+  DevBuf<int> d_lane_skip_;
+  DevBuf<double> d_snap_all_;
   void build_lane_records();                  // enqueue lane_rec_kernel on stream_ behind the lane descriptors (and the lane order)
   DevBuf<int> d_shape_epar_;
   DevBuf<int> d_lane_shape_, d_lane_player_, d_lane_row_, d_lane_act_;
@@ -302,6 +311,7 @@ class SelfPlay {
   // the last epoch's examples as device pointers ([2n][Q], [2n][H]), valid until the next advance(); null in host mode
   void device_examples(const float** q, const float** v) const;
   int64_t games_finished() const { return games_; }
+  int64_t lanes_served_by_root_dedup() const { return skipped_; }  // lane-epochs that read the representative's root solve
   void state(int lane, int32_t* last_bid, int32_t* player) const;
   int num_lanes() const { return n_; }
 
@@ -333,7 +343,7 @@ class SelfPlay {
   std::vector<double> beliefs_;  // [n][2][H]
   std::vector<float> ex_q_, ex_v_;
   std::vector<int32_t> ex_lane_;
-  int64_t games_ = 0;
+  int64_t games_ = 0, skipped_ = 0;
 };
 
 }  // namespace rbl

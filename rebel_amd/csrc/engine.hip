@@ -127,7 +127,6 @@ void Engine::construct() {
       r.act_iter = -1;
       r.node_off = s.node_off;
       r.term_off = s.term_off;
-      r.leaf_off = s.leaf_off;
       r.shape = (int)si;
     }
     // cfr_wave_kernel: byte tables (every entry a node id, an action or -1: needs N <= 127) and the 15-bit parent offsets
@@ -662,6 +661,8 @@ void Engine::reset(int B, const int32_t* root_last_bid, const int32_t* root_play
   d_lane_row_.upload(h_row_, stream_);
   d_lane_act_.upload(h_act_, stream_);
   d_beliefs_.upload(h_beliefs_, stream_);
+  if (root_dedup_)  // a host-described batch solves every lane (the flags belong to device-resident self-play epochs)
+    RBL_HIP_CHECK(hipMemsetAsync(d_lane_skip_.p, 0, (size_t)max_lanes_ * sizeof(int), stream_));
   // lane parts (parts_for; one part from 16384 lanes on, see the constructor): independent lane sets on their
   // own streams, rows of a part are contiguous
   n_parts_ = parts_for(B);
@@ -784,8 +785,22 @@ void Engine::begin_epoch_device(int B, const SpEpochInfo* info_dev) {
 void Engine::build_lane_records() {
   if (!wave_ok_ && !flat_ok_) return;
   launch_lane_rec(d_shape_rec_.p, d_lane_shape_.p, d_lane_player_.p, d_lane_row_.p, d_lane_act_.p,
-                  use_order_ ? d_lane_order_.p : nullptr, B_, d_lane_rec_.p, stream_);
+                  use_order_ ? d_lane_order_.p : nullptr, root_dedup_ ? d_lane_skip_.p : nullptr, B_, d_lane_rec_.p, stream_);
   RBL_HIP_CHECK(hipGetLastError());
+}
+
+// Root de-duplication (selfplay_kernels.h): only for CFR solvers whose step runs on a kernel that reads the
+// per-slot records (the flags live there) -- i.e. every BASELINE configuration.
+bool Engine::enable_root_dedup() {
+  if (root_dedup_) return true;
+  if (!p_.use_cfr || !(wave_ok_ || (flat_ok_ && rows_global_ok_))) return false;
+  RBL_HIP_CHECK(hipSetDevice(device_));
+  sync();
+  d_lane_skip_.alloc((size_t)max_lanes_);
+  RBL_HIP_CHECK(hipMemset(d_lane_skip_.p, 0, (size_t)max_lanes_ * sizeof(int)));
+  d_snap_all_.alloc((size_t)(p_.num_iters + 1) * emax_ * g_.H);
+  root_dedup_ = true;
+  return true;
 }
 
 void Engine::split_part_queries(int part, hipStream_t st) {
@@ -903,6 +918,8 @@ void Engine::launch(int mode, int trav, int next_trav, int steps_after, double a
   a.regrets = d_regrets_.p;
   a.sums = d_sums_.p;
   a.snapshot = d_snapshot_.p;
+  a.lane_skip = root_dedup_ ? d_lane_skip_.p : nullptr;
+  a.snap_all = root_dedup_ ? d_snap_all_.p : nullptr;
   a.root_mean = d_root_mean_.p;
   a.queries = d_queries_.p;
   // (qsplit_ changes only when the net KIND changes -- set_net_* under net_mutex_, after sync() has drained both streams.  A
@@ -1687,6 +1704,9 @@ void SelfPlay::init_device() {
   RBL_HIP_CHECK(hipStreamSynchronize(st));  // the staging vectors above go out of scope
   ex_lane_.resize((size_t)2 * n_);
   for (int i = 0; i < n_; ++i) ex_lane_[2 * i] = ex_lane_[2 * i + 1] = i;
+  // REBEL_AMD_ROOT_DEDUP=1 (default off; a labelled extra, never the measured headline): the root subgame is solved once per epoch
+  if (env_int("REBEL_AMD_ROOT_DEDUP", 0) != 0 && !e_->enable_root_dedup())
+    std::fprintf(stderr, "rebel_amd: REBEL_AMD_ROOT_DEDUP=1 ignored: this engine's CFR step does not run on a record-driven kernel\n");
 }
 
 SpArgs SelfPlay::sp_args() const {
@@ -1723,6 +1743,9 @@ SpArgs SelfPlay::sp_args() const {
   a.ex_q = d_ex_q_.p;
   a.ex_v = d_ex_v_.p;
   a.info = d_info_.p;
+  a.dedup = e_->root_dedup() ? 1 : 0;
+  a.lane_skip = e_->lane_skip_dev();
+  a.snap_all = e_->snap_all_dev();
   a.lane_order = e_->lane_order_dev();
   a.n_parts = e_->parts_for(n_);
   e_->part_lanes(n_, a.part_lane);
@@ -1763,10 +1786,12 @@ int64_t SelfPlay::advance_device(rbl_example_fn sink, void* user) {
   RBL_HIP_CHECK(hipStreamSynchronize(st));
   e_->end_epoch_device(*hi);
   games_ = (int64_t)hi->games;
+  skipped_ += hi->skipped;
   std::copy(hb, hb + n_, bid_.begin());
   std::copy(hp, hp + n_, player_.begin());
   if (sink) sink(user, (int64_t)2 * n_, ex_lane_.data(), hq, Q, hv, H);
-  return (int64_t)n_ * num_iters;
+  // subgame-CFR-iterations EXECUTED this epoch: with root de-duplication the served root lanes ran none
+  return (int64_t)(n_ - hi->skipped) * num_iters;
 }
 
 int64_t SelfPlay::advance_host(rbl_example_fn sink, void* user) {
@@ -2149,6 +2174,7 @@ int rbl_selftest_device_rng(int device, int32_t seed, int rounds, int hi, const 
   });
 }
 int64_t rbl_selfplay_games_finished(rbl_selfplay* sp) { return sp ? sp->impl.games_finished() : -1; }
+int64_t rbl_selfplay_root_dedup_served(rbl_selfplay* sp) { return sp ? sp->impl.lanes_served_by_root_dedup() : -1; }
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id) {
   return guard([&] { need(sp).state(lane, last_bid, player_id); });
 }

@@ -373,12 +373,19 @@ class ValuePrioritizedReplay {
   // topology (cfvpy/selfplay.py:193-252: cuda:0 trains, cuda:1.. generate, ONE replay) that is cuda:1; the other generators
   // append with peer copies over xGMI (16 MB per epoch of 16 384 lanes) and sample(batch, "cuda:0") gathers on the ring's GPU
   // and moves only the batch.  REBEL_AMD_REPLAY_DEVICE=<index> homes the rings on a chosen GPU instead (e.g. 0, the
-  // training GPU: sampling becomes local, every append a peer copy); REBEL_AMD_REPLAY_HOST=1 keeps them in host memory.
+  // training GPU: sampling becomes local, every append a peer copy); REBEL_AMD_REPLAY_HOST=1 keeps them in host memory and the
+  // generators read their examples back themselves.  REBEL_AMD_REPLAY_DEVICE=host homes the rings in host memory while the
+  // generators keep handing over DEVICE blocks: every append then takes the cross-device branch of append() (source on a GPU,
+  // ring elsewhere: copy_ across devices, both devices' streams waited for) -- the branch a peer GPU's ring takes on an 8-GPU
+  // node, reachable on a one-GPU box (tests/test_rela_gpu.py).
   void ensure_layout(int64_t Q, int64_t V, int device_index) {
-    const bool want_gpu = device_index >= 0 && !std::getenv("REBEL_AMD_REPLAY_HOST");
+    bool want_gpu = device_index >= 0 && !std::getenv("REBEL_AMD_REPLAY_HOST");
     if (want_gpu)
       if (const char* home = std::getenv("REBEL_AMD_REPLAY_DEVICE"))
-        if (*home) device_index = std::atoi(home);
+        if (*home) {
+          if (std::string(home) == "host") want_gpu = false;
+          else device_index = std::atoi(home);
+        }
     if (Q_ < 0) {
       Q_ = Q;
       V_ = V;

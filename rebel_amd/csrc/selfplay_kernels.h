@@ -28,6 +28,8 @@ struct SpEpochInfo {
   unsigned long long games;                         // games finished so far (all epochs)
   long long rows;                                   // = part_row[n_parts]
   int seg_shape[kSpMaxParts][kSpSegs];              // shape of the largest tree of each launch segment (sp_order)
+  int root_rep;                                     // root de-duplication: the lane that solves the root subgame this epoch (-1: none)
+  int skipped;                                      // ... and how many root lanes read its result instead of solving their own
 };
 
 struct SpArgs {
@@ -60,6 +62,15 @@ struct SpArgs {
   float* ex_q;  // [2n][Q]
   float* ex_v;  // [2n][H]
   SpEpochInfo* info;
+  // ---- root de-duplication (REBEL_AMD_ROOT_DEDUP=1, default off).  Every lane whose subgame starts at the
+  // ROOT state computes the same thing: RlRunner::step resets to the root with uniform beliefs (recursive_solving.cc:160-163) and
+  // CFR::step draws nothing, and the lanes are in lock-step under one net.  With dedup on, the lowest-indexed root lane of the
+  // epoch (the representative, lane_skip == 2) solves it and keeps sigma after EVERY iteration (snap_all [num_iters + 1][Emax*H]);
+  // the other root lanes (lane_skip == 1) get no net rows and no CFR launches, and sp_end reads the representative's sigma at
+  // THEIR act_iteration and its root values: their trajectories and examples are bit-identical to the mode-off run.
+  int dedup;
+  int* lane_skip;          // [n] 0 = solves its own subgame, 1 = root lane served by the representative, 2 = the representative
+  const double* snap_all;  // [num_iters + 1][Emax*H]
   int* lane_order;  // [n] lanes of each part sorted by tree size, largest first (null: not wanted)
   int n_parts;
   int part_lane[kSpMaxParts + 1];

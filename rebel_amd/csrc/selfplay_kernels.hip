@@ -143,10 +143,28 @@ __global__ void __launch_bounds__(256) sp_begin_kernel(const SpArgs a) {
 // One workgroup: exclusive prefix sum of L(shape(lane)) over the lanes in order -> lane_row; part boundaries; byte sums.
 __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
   __shared__ long long part[1024];
+  __shared__ int rep_s, skipped_s;
   const int t = threadIdx.x, per = (a.n + 1023) / 1024;
   const int l0 = t * per, l1 = l0 + per < a.n ? l0 + per : a.n;
+  // root de-duplication (selfplay_kernels.h): the lowest-indexed lane in the root state is the epoch's representative; the other
+  // root lanes take no net rows (shape 0 <=> last bid -1 <=> the root state, whose beliefs are uniform by construction)
+  if (t == 0) {
+    rep_s = 0x7fffffff;
+    skipped_s = 0;
+  }
+  __syncthreads();
+  if (a.dedup) {
+    for (int i = l0; i < l1; ++i)
+      if (a.lane_shape[i] == 0) {
+        atomicMin(&rep_s, i);
+        break;
+      }
+  }
+  __syncthreads();
+  const int rep = a.dedup && rep_s < a.n ? rep_s : -1;
+  auto skip_of = [&](int i) { return rep < 0 || a.lane_shape[i] != 0 ? 0 : (i == rep ? 2 : 1); };
   long long mine = 0;
-  for (int i = l0; i < l1; ++i) mine += a.shapes[a.lane_shape[i]].L;
+  for (int i = l0; i < l1; ++i) mine += skip_of(i) == 1 ? 0 : a.shapes[a.lane_shape[i]].L;
   part[t] = mine;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
@@ -156,15 +174,21 @@ __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
     __syncthreads();
   }
   long long row = part[t] - mine;
+  int my_skipped = 0;
   for (int i = l0; i < l1; ++i) {
+    const int sk = skip_of(i);
     a.lane_row[i] = (int)row;
+    if (a.lane_skip) a.lane_skip[i] = sk;
+    my_skipped += sk == 1;
     for (int p = 0; p < a.n_parts; ++p)
       if (i == a.part_lane[p]) a.info->part_row[p] = row;
-    row += a.shapes[a.lane_shape[i]].L;
+    row += sk == 1 ? 0 : a.shapes[a.lane_shape[i]].L;
   }
+  if (my_skipped) atomicAdd(&skipped_s, my_skipped);
   if (t == 1023) {
     a.info->part_row[a.n_parts] = part[1023];
     a.info->rows = part[1023];
+    a.info->root_rep = rep;
   }
   // algorithmic bytes of one CFR step per part and traverser: read sigma over E, RMW regrets and sums +
   // write sigma over E_t, write L queries, read L value rows
@@ -172,6 +196,7 @@ __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
   if (t < kSpMaxParts * 2) bytes[t >> 1][t & 1] = 0;
   __syncthreads();
   for (int i = l0; i < l1; ++i) {
+    if (skip_of(i) == 1) continue;  // no launch touches this lane
     const int s = a.lane_shape[i];
     const ShapeDev& sh = a.shapes[s];
     int p = 0;
@@ -185,6 +210,7 @@ __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
   }
   __syncthreads();
   if (t < kSpMaxParts * 2) a.info->part_bytes[t >> 1][t & 1] = bytes[t >> 1][t & 1];
+  if (t == 0) a.info->skipped = skipped_s;
 }
 
 // Lanes of each part in order of tree size, largest first, ties by lane index: a stable counting sort by shape id (a
@@ -193,12 +219,15 @@ __global__ void __launch_bounds__(1024) sp_scan_kernel(const SpArgs a) {
 // of the kSpSegs equal launch segments of a part: the host sizes each launch's LDS request by it.
 __global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
   __shared__ int start[kSpMaxParts][128];
-  const int s = threadIdx.x, n_shapes = a.A;  // shapes 0 .. A-1 (root_last_bid + 1)
+  // shapes 0 .. A-1 (root_last_bid + 1); one more key, A, for the root lanes that root de-duplication serves from the
+  // representative: their workgroups exit at once, so they sort behind every real tree (launch_sp_order: A + 1 <= 128)
+  const int s = threadIdx.x, n_shapes = a.A + (a.dedup ? 1 : 0);
+  auto key = [&](int i) { return a.dedup && a.lane_skip[i] == 1 ? a.A : a.lane_shape[i]; };
   for (int p = 0; p < a.n_parts; ++p) {
     const int l0 = a.part_lane[p], l1 = a.part_lane[p + 1];
     int cnt = 0;
     if (s < n_shapes)
-      for (int i = l0; i < l1; ++i) cnt += a.lane_shape[i] == s;
+      for (int i = l0; i < l1; ++i) cnt += key(i) == s;
     start[p][s] = cnt;
     __syncthreads();
     if (s == 0) {
@@ -213,7 +242,7 @@ __global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
     if (s < n_shapes) {
       int w = start[p][s];
       for (int i = l0; i < l1; ++i)
-        if (a.lane_shape[i] == s) a.lane_order[w++] = i;
+        if (key(i) == s) a.lane_order[w++] = i;
     }
     __syncthreads();
     if (s < kSpSegs) {
@@ -249,7 +278,11 @@ __global__ void __launch_bounds__(128) sp_end_kernel(const SpArgs a) {
   const int* t_cb = a.cb + s.node_off;
   const int* t_ce = a.ce + s.node_off;
   const int* t_depth = a.depth + s.node_off;
-  const double* sigma = a.snapshot + (size_t)i * a.Emax * H;
+  // root de-duplication: a served root lane reads the representative's sigma after ITS act_iteration and the representative's
+  // root values -- bit for bit what its own solve would have left in its own slabs
+  const bool served = a.dedup && a.lane_skip[i] == 1;
+  const int src = served ? a.info->root_rep : i;
+  const double* sigma = served ? a.snap_all + (size_t)a.lane_act[i] * a.Emax * H : a.snapshot + (size_t)i * a.Emax * H;
   double* bel = a.beliefs + (size_t)i * 2 * H;
   // ---- the subgame's training examples (root state of the epoch = the engine's descriptors)
   {
@@ -257,7 +290,7 @@ __global__ void __launch_bounds__(128) sp_end_kernel(const SpArgs a) {
     for (int t = 0; t < 2; ++t) {
       const size_t k = (size_t)2 * i + t;
       write_root_query(a, t, root_bid, root_player, rb, rb + H, a.ex_q + k * Q);
-      for (int h = 0; h < H; ++h) a.ex_v[k * H + h] = (float)a.root_mean[((size_t)i * 2 + t) * H + h];  // :224
+      for (int h = 0; h < H; ++h) a.ex_v[k * H + h] = (float)a.root_mean[((size_t)src * 2 + t) * H + h];  // :224
     }
   }
   Rng r{a.mt + i, a.n, a.mt_idx[i]};
@@ -348,7 +381,7 @@ void launch_sp_begin(const SpArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(sp_begin_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
 }
 void launch_sp_order(const SpArgs& a, hipStream_t st) {
-  if (a.A > 128) return;
+  if (a.A + 1 > 128) return;
   hipLaunchKernelGGL(sp_order_kernel, dim3(1), dim3(128), 0, st, a);
 }
 

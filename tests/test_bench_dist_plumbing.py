@@ -73,6 +73,40 @@ def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
     assert seeds[0]["seeds"] == list(range(lanes)) and seeds[1]["seeds"] == list(range(lanes, 2 * lanes))
 
 
+def test_bench_eight_ranks_report_per_gpu_and_job_level_roofline_fractions(tmp_path):
+    """VERDICT r5 #4a / north_star ("1/2/4/8-GPU throughput reported as absolute numbers and as fraction of HBM roofline"): the
+    driver's 8-GPU command shape, `bench.py --gpus 8`, on eight gloo ranks against the counting engine.  Rank 0's ONE line carries
+    every rank's value, net_frac_mfma, cfr_frac_hbm, cfr_gbps and the job's CFR sweep as a fraction of 8 x the HBM roofline."""
+    lanes, iters, steps, world = 16, 4, 2, 8
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_stub_driver.py"), "--gpus", str(world), "--steps", str(steps),
+           "--warmup", "1", "--lanes", str(lanes), "--iters", str(iters), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=_clean_env(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == world and res["scaling"] == "weak" and res["config"]["parallelism"] == f"independent lane sets x{world}"
+    ranks = res["per_gpu"]["ranks"]
+    assert res["per_gpu"]["ranks_seen_by_rccl"] == world and res["per_gpu"]["backend"] == "gloo"  # (the stub maps "nccl" to gloo)
+    assert [x["rank"] for x in ranks] == list(range(world)) and [x["gpu"] for x in ranks] == list(range(world))
+    for x in ranks:
+        assert {"value", "seconds", "net_frac_mfma", "cfr_frac_hbm", "cfr_gbps", "net_launch_us", "cfr_launch_us"} <= set(x)
+        assert x["value"] > 0 and 0 < x["net_frac_mfma"] < 1 and 0 < x["cfr_frac_hbm"] < 1 and x["cfr_gbps"] > 0
+    job = res["job"]
+    assert job["n_gpus"] == world and job["value"] == res["value"]
+    assert abs(job["cfr_gbps_sum"] - sum(x["cfr_gbps"] for x in ranks)) < 1e-9 * job["cfr_gbps_sum"]
+    assert abs(job["cfr_frac_of_n_x_hbm_roofline"] - job["cfr_gbps_sum"] / (world * 8000.0)) < 1e-12
+    assert abs(job["net_frac_of_n_x_mfma_peak"] - sum(x["net_frac_mfma"] for x in ranks) / world) < 1e-12
+    assert job["value_per_gpu_min"] <= job["value_per_gpu_mean"] <= job["value_per_gpu_max"]
+    # whole-job work over the slowest rank's time (rank 7 sleeps eight times rank 0's step)
+    units = world * lanes * iters * steps
+    assert abs(res["value"] * res["ms_per_step"] * 1e-3 * steps - units) < 1e-6 * units
+    assert abs(job["slowest_rank_seconds"] - res["ms_per_step"] * 1e-3 * steps) < 1e-6 * job["slowest_rank_seconds"] + 1e-3
+    seeds = [json.load(open(str(tmp_path / "seeds") + f".{k}")) for k in range(world)]
+    assert all(seeds[k]["seeds"] == list(range(k * lanes, (k + 1) * lanes)) and seeds[k]["device"] == k for k in range(world))
+
+
 def test_bench_refuses_more_gpus_than_visible(tmp_path):
     """... and on a box with fewer GPUs than asked for it exits non-zero with a message, instead of measuring one GPU and
     calling it N (what the dead flag of rounds 1-3 did)."""

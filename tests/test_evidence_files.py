@@ -50,21 +50,26 @@ def test_bench_line_quotes_the_committed_profiles():
 
     for key, kern in (("roofline", ("mlp_resident_kernel",)), ("roofline_cfr", ("cfr_wave_kernel",))):
         r = d[key]
-        if "traffic_detail" in r:
-            src = os.path.join(ROOT, r["traffic_detail"]["source"])
+        # round 6 on: what the line quotes from committed profiles sits in ONE sub-object, apart from the live figures, and the
+        # live `traffic` is null; rounds <= 5 had the same fields beside `frac`
+        fcp = r.get("from_committed_profile", r)
+        if "from_committed_profile" in r:
+            assert r["traffic"] is None and "rocprof" not in r and "traffic_detail" not in r and "NOT measured in this run" in fcp["note"]
+        if "traffic_detail" in fcp:
+            src = os.path.join(ROOT, fcp["traffic_detail"]["source"])
             assert os.path.exists(src), src
-            k = json.load(open(src))["kernels"][r["traffic_detail"]["kernel"]]
+            k = json.load(open(src))["kernels"][fcp["traffic_detail"]["kernel"]]
             rd = k["fetch_size_bytes_per_launch"]["timed_epochs"]["mean"]
             wr = k["write_size_bytes_per_launch"]["timed_epochs"]["mean"]
-            assert abs(r["traffic"] - (rd + wr)) < 1e-6 * r["traffic"]
-        if "rocprof" in r:
-            src = os.path.join(ROOT, r["rocprof"]["source"])
+            assert abs(fcp["traffic"] - (rd + wr)) < 1e-6 * fcp["traffic"]
+        if "rocprof" in fcp:
+            src = os.path.join(ROOT, fcp["rocprof"]["source"])
             assert os.path.exists(src), src
-            want_us = r["rocprof"]["avg_launch_us"]
-            assert any(abs(float(line.rsplit(",", 5)[4]) / 1e3 - want_us) < 1e-6 and r["rocprof"]["kernel"] in line
+            want_us = fcp["rocprof"]["avg_launch_us"]
+            assert any(abs(float(line.rsplit(",", 5)[4]) / 1e3 - want_us) < 1e-6 and fcp["rocprof"]["kernel"] in line
                        for line in open(src).read().splitlines()[1:])
             work = r.get("algorithmic_flops_per_launch", r.get("algorithmic_bytes_per_launch")) / (1e12 if key == "roofline" else 1e9)
-            assert abs(r["rocprof"]["frac"] - work / (want_us * 1e-6) / r["peak"]) < 1e-9
+            assert abs(fcp["rocprof"]["frac"] - work / (want_us * 1e-6) / r["peak"]) < 1e-9
         # the readers find the newest committed summaries of the driver's command shape
         # (the steps / warm-up shape is whatever the newest committed PMC summary says it profiled: no literals here)
         shape = tuple(json.load(open(os.path.join(ROOT, bench.pmc_traffic(kern)["source"])))["steps_warmup"])

