@@ -466,6 +466,20 @@ def main():
         hdt, hunits, _, _, hst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False, precision=2)
         half_leg = (hdt, hunits, hst)
 
+    dedup_leg = None
+    if world == 1 and not a.no_extra_legs:
+        # LABELLED EXTRA LEG, never the headline: REBEL_AMD_ROOT_DEDUP=1.  Every lane in its ROOT subgame computes the
+        # same thing (RlRunner::step resets to the root with uniform beliefs, recursive_solving.cc:160-163; CFR::step draws nothing),
+        # so one lane per epoch solves the root and the other root lanes sample from its sigma at their own act_iteration: the
+        # example stream per seed is bit-identical (tests/test_selfplay_parity.py::test_root_dedup_*), the iterations EXECUTED drop.
+        # `value`, `roofline` and `rela_boundary` above keep executing every lane's iterations, as the reference's threads do.
+        os.environ["REBEL_AMD_ROOT_DEDUP"] = "1"
+        try:
+            ddt, dunits, dgames, dex, dst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False)
+            dedup_leg = (ddt, dunits, dgames, dex, dst, list(leg_roots))
+        finally:
+            del os.environ["REBEL_AMD_ROOT_DEDUP"]
+
     rela_leg = None
     if world == 1 and rank == 0 and not a.no_extra_legs and a.rela_epochs > 0:
         try:
@@ -616,6 +630,20 @@ def main():
                 "net": {k: hnet[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_us", "ns_per_row", "issued_mfma_tflops")},
                 "cfr": {k: hcfr[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_us")},
                 "net_products": hst.get("net_products")}
+        if dedup_leg:
+            ddt, dunits, dgames, dex, dst, droots = dedup_leg
+            dnet, dcfr = roofline_blocks(headline, dst, int(dst["n_streams"]))
+            out["root_dedup"] = {
+                "label": "EXTRA LEG, not the headline and not the metric: REBEL_AMD_ROOT_DEDUP=1 (opt-in).  The root subgame is solved "
+                         "by ONE lane per epoch; the other root lanes read its strategy at their own act_iteration.  Training "
+                         "examples and trajectories per seed are bit-identical to the headline run; only executed work drops",
+                "games_per_s": dgames / ddt, "examples_per_s": dex / ddt, "executed_iterations_per_s": dunits / ddt,
+                "ms_per_step": ddt / a.steps * 1e3,
+                "examples_per_s_vs_headline": (dex / ddt) / (n_examples / dt),
+                "lane_epochs_served_by_the_representative": 1.0 - dunits / (a.lanes * a.iters * a.steps),
+                "roots_per_epoch": droots,
+                "net": {k: dnet[k] for k in ("kernel", "frac", "avg_launch_us", "rows_per_launch", "ns_per_row")},
+                "cfr": {k: dcfr[k] for k in ("kernel", "frac", "avg_launch_us", "algorithmic_bytes_per_launch")}}
         if lanes4096:
             out["lanes_4096"] = lanes4096
         if two_streams:

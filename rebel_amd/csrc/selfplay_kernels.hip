@@ -222,7 +222,20 @@ __global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
   // shapes 0 .. A-1 (root_last_bid + 1); one more key, A, for the root lanes that root de-duplication serves from the
   // representative: their workgroups exit at once, so they sort behind every real tree (launch_sp_order: A + 1 <= 128)
   const int s = threadIdx.x, n_shapes = a.A + (a.dedup ? 1 : 0);
-  auto key = [&](int i) { return a.dedup && a.lane_skip[i] == 1 ? a.A : a.lane_shape[i]; };
+  // the epoch's representative, recomputed here from the lane shapes (the lowest-indexed root lane, as in sp_scan) rather than
+  // read from sp_scan's lane_skip[]: this kernel then depends on nothing the kernel in front of it wrote
+  __shared__ int rep_s;
+  if (s == 0) rep_s = 0x7fffffff;
+  __syncthreads();
+  if (a.dedup)
+    for (int i = s; i < a.n; i += blockDim.x)
+      if (a.lane_shape[i] == 0) {
+        atomicMin(&rep_s, i);
+        break;
+      }
+  __syncthreads();
+  const int rep = rep_s;
+  auto key = [&](int i) { return a.dedup && a.lane_shape[i] == 0 && i != rep ? a.A : a.lane_shape[i]; };
   for (int p = 0; p < a.n_parts; ++p) {
     const int l0 = a.part_lane[p], l1 = a.part_lane[p + 1];
     int cnt = 0;

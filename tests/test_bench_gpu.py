@@ -96,6 +96,11 @@ def test_rela_boundary_leg_measures_the_metric_through_the_pybind_surface():
     assert abs(rb["ratio_to_value"] - rb["value"] / d["value"]) < 1e-12
     assert 0.5 < rb["ratio_to_value"] < 1.5, rb  # loose: a 256-iteration epoch is short; the driver's line has the real figure
     assert rb["without_consumer"]["value"] > 0
+    # the labelled root de-duplication extra: same examples, fewer executed iterations, never the headline's value
+    rd = d["root_dedup"]
+    assert "EXTRA LEG" in rd["label"] and rd["examples_per_s_vs_headline"] > 1.0 and rd["games_per_s"] > d["games_per_s"]
+    assert 0 < rd["lane_epochs_served_by_the_representative"] < 1 and rd["executed_iterations_per_s"] > 0
+    assert len(rd["roots_per_epoch"]) == d["steps"] and d["value"] == pytest.approx(4096 * 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]))
 
 
 @pytest.mark.parametrize("world", [2, 4])
