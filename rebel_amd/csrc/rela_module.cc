@@ -1082,14 +1082,155 @@ float compute_exploitability(RecursiveSolvingParams params, const std::string& m
   return exploitability_with_net_impl(params, model_path, /*to_leaf=*/false);
 }
 
-// pybind.cc:57-84.  The first element (exploitability of the to-leaf recursive strategy) is computed on the device; the
-// two net-quality MSEs come from stats.cc's eval_net, a CPU diagnostic that is out of scope here:
-// they are returned as NaN, never as made-up numbers.
+// ---- eval_net (stats.cc:44-153): how far the value net is from a full solve at the public states recursive solving reaches.
+// For every non-terminal node at depth mdp_depth and 2 * mdp_depth of the full tree whose reach under the traversing strategy is
+// >= 1e-6: beliefs = both players' normalised reach there; "br_value" = the traverser's root value of a full-depth linear
+// fictitious-play solve of that subgame (fp_iters iterations), "net_value" = the net's answer to the same query, both weighted
+// with the traverser's beliefs; the result is the mean squared difference over nodes and traversers.
+// Here: the reach sweeps (compute_reach_probabilities, subgame_solving.cc:54-78) and the node selection are host loops over the
+// dense strategies; ALL selected subgames are solved at once as lanes of one full-depth FP engine on the device, and the net
+// answers all queries in one batched forward.
+float eval_net_impl(const RecursiveSolvingParams& params, rbl_engine* net_engine, const std::vector<double>& net_strategy,
+                    const std::vector<double>& full_strategy, int mdp_depth, int fp_iters, bool traverse_by_net) {
+  const int d = params.num_dice, f = params.num_faces;
+  const int H = rbl_num_hands(d, f), A = rbl_num_actions(d, f), Q = rbl_query_size(d, f), liar = A - 1;
+  const int n = rbl_unroll_tree(d, f, -1, 0, 1000000, nullptr, 0);
+  std::vector<int32_t> tree((size_t)n * 6);  // (last_bid, player, children_begin, children_end, parent, depth) per node
+  if (rbl_unroll_tree(d, f, -1, 0, 1000000, tree.data(), n) != n) fail("eval_net: unroll_tree");
+  auto T = [&](int node, int k) { return tree[(size_t)node * 6 + k]; };
+  struct Stats {
+    std::vector<double> reach[2];  // [node][hand]
+    std::vector<double> node_reach;
+  };
+  auto stats_of = [&](const std::vector<double>& strategy) {  // compute_stategy_stats (subgame_solving.cc:823-846), reach part
+    Stats st;
+    for (int p = 0; p < 2; ++p) {
+      st.reach[p].assign((size_t)n * H, 0.0);
+      for (int h = 0; h < H; ++h) st.reach[p][h] = 1.0 / H;  // get_initial_beliefs: uniform
+      for (int node = 1; node < n; ++node) {
+        const int par = T(node, 4), act = T(node, 0);
+        for (int h = 0; h < H; ++h)
+          st.reach[p][(size_t)node * H + h] = T(par, 1) == p
+                                                 ? st.reach[p][(size_t)par * H + h] * strategy[((size_t)par * H + h) * A + act]
+                                                 : st.reach[p][(size_t)par * H + h];
+      }
+    }
+    st.node_reach.resize(n);
+    for (int node = 0; node < n; ++node) {
+      double s0 = 0, s1 = 0;
+      for (int h = 0; h < H; ++h) s0 += st.reach[0][(size_t)node * H + h];
+      for (int h = 0; h < H; ++h) s1 += st.reach[1][(size_t)node * H + h];
+      st.node_reach[node] = s0 * s1;
+    }
+    return st;
+  };
+  const Stats net_stats = stats_of(net_strategy), true_stats = stats_of(full_strategy);
+  const Stats& trav = traverse_by_net ? net_stats : true_stats;
+  std::printf(traverse_by_net ? "Using net policy to define beliefs\n" : "Using FP policy to define beliefs\n");
+  std::vector<int> top;
+  for (int node = 0; node < n; ++node)
+    if ((T(node, 5) == mdp_depth || T(node, 5) == 2 * mdp_depth) && T(node, 0) != liar) top.push_back(node);
+  std::stable_sort(top.begin(), top.end(), [&](int i, int j) { return trav.node_reach[i] > trav.node_reach[j]; });
+  std::printf("Non-terminal nodes at depth %d: %zu\n", mdp_depth, top.size());
+  if (top.empty()) {
+    std::printf("Empty list. Exiting.\n");
+    return 0.0f;
+  }
+  const float kMinReach = 1e-6;
+  while (!top.empty() && trav.node_reach[top.back()] < kMinReach) top.pop_back();
+  if (top.empty()) return 0.0f;
+  double total_true = 0, total_net = 0;
+  for (int node : top) {
+    total_true += true_stats.node_reach[node];
+    total_net += net_stats.node_reach[node];
+  }
+  std::printf("After filtering with reach < %g: %zu\nMin reach: %g\nMax reach: %g\nTotal reach: true=%g net=%g\n", (double)kMinReach,
+              top.size(), trav.node_reach[top.back()], trav.node_reach[top.front()], total_true, total_net);
+  // the selected subgames as lanes of one full-depth linear-FP engine (stats.cc:112-118)
+  const int B = (int)top.size();
+  std::vector<int32_t> bids(B), players(B);
+  std::vector<double> beliefs((size_t)B * 2 * H);
+  for (int b = 0; b < B; ++b) {
+    const int node = top[b];
+    bids[b] = T(node, 0);
+    players[b] = T(node, 1);
+    for (int p = 0; p < 2; ++p) {  // normalize_probabilities (util.h:25-34): x / sum, no smoothing
+      double sum = 0;
+      for (int h = 0; h < H; ++h) sum += trav.reach[p][(size_t)node * H + h];
+      for (int h = 0; h < H; ++h) beliefs[((size_t)b * 2 + p) * H + h] = trav.reach[p][(size_t)node * H + h] / sum;
+    }
+  }
+  SubgameSolvingParams fp_params;
+  fp_params.num_iters = fp_iters;
+  fp_params.max_depth = 1000000;
+  fp_params.linear_update = true;
+  EvalEngine fp(params, fp_params, B);
+  check(rbl_engine_set_net_zero(fp.e), "set_net_zero");
+  check(rbl_solver_reset(fp.e, B, bids.data(), players.data(), beliefs.data(), nullptr), "reset");
+  check(rbl_solver_multistep(fp.e, -1), "multistep");
+  // the net's answers to the same 2 B queries (get_query = write_query_to, subgame_solving.cc:104-123), one batched forward
+  std::vector<float> queries((size_t)2 * B * Q), values((size_t)2 * B * H);
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < 2; ++t) {
+      float* q = queries.data() + ((size_t)2 * b + t) * Q;
+      int w = 0;
+      q[w++] = (float)players[b];
+      q[w++] = (float)t;
+      for (int a = 0; a < A; ++a) q[w++] = a == bids[b] ? 1.0f : 0.0f;
+      for (int p = 0; p < 2; ++p) {  // normalize_probabilities_safe with kReachSmoothingEps (util.h:68-78)
+        const double* r = beliefs.data() + ((size_t)b * 2 + p) * H;
+        double sum = 0;
+        for (int h = 0; h < H; ++h) sum += r[h] + 1e-80;
+        for (int h = 0; h < H; ++h) q[w++] = (float)((r[h] + 1e-80) / sum);
+      }
+    }
+  check(rbl_net_forward(net_engine, queries.data(), (int64_t)2 * B, values.data()), "net_forward");
+  float sum_sq = 0;  // vector_sum<float> of the squared differences (stats.cc:148-149)
+  std::vector<double> hv(H);
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < 2; ++t) {
+      check(rbl_solver_hand_values(fp.e, b, t, hv.data()), "hand_values");
+      const double* r = beliefs.data() + ((size_t)b * 2 + t) * H;
+      double nv = 0, bv = 0;  // (float tensor * double tensor).sum().item<float>(): double arithmetic, float result
+      for (int h = 0; h < H; ++h) nv += (double)values[((size_t)2 * b + t) * H + h] * r[h];
+      for (int h = 0; h < H; ++h) bv += hv[h] * r[h];
+      const float net_value = (float)nv, br_value = (float)bv;
+      sum_sq += (float)std::pow(net_value - br_value, 2.0);
+    }
+  const float mse = sum_sq / (2 * B);
+  std::printf("Final MSE: %g\n", (double)mse);
+  return mse;
+}
+
+// pybind.cc:57-84: (exploitability of the to-leaf recursive strategy, eval_net MSE with beliefs from the net's strategy, eval_net
+// MSE with beliefs from the full-tree solution).  Round 6: the two MSEs are computed (they were NaN through round 5; the
+// trainer logs them every 20 epochs, cfvpy/selfplay.py:555-570).  print_strategy's strategy.txt is not written.
 std::tuple<float, float, float> compute_stats_with_net(RecursiveSolvingParams params, const std::string& model_path) {
   py::gil_scoped_release release;
-  const float ex = exploitability_with_net_impl(params, model_path, /*to_leaf=*/true);
-  const float nan = std::nanf("");
-  return std::make_tuple(ex, nan, nan);
+  const int n = full_tree_size(params);
+  const int H = rbl_num_hands(params.num_dice, params.num_faces), A = rbl_num_actions(params.num_dice, params.num_faces);
+  EvalEngine ev(params, params.subgame_params, 4096);
+  load_torchscript_net(ev.e, model_path);
+  std::vector<double> net_strategy((size_t)n * H * A), full_strategy((size_t)n * H * A);
+  check(rbl_strategy_recursive(ev.e, /*to_leaf=*/1, net_strategy.data()), "strategy_recursive");
+  double ex[2];
+  check(rbl_exploitability2(eval_device(), params.num_dice, params.num_faces, net_strategy.data(), ex), "exploitability2");
+  const float exploitability = (float)((ex[0] + ex[1]) / 2.);
+  {  // the full-tree solution with the caller's solver settings (pybind.cc:69-73)
+    auto full_params = params.subgame_params;
+    full_params.max_depth = 1000000;
+    EvalEngine full(params, full_params, 1);
+    std::vector<double> b(2 * (size_t)H, 1. / H);
+    const int32_t rb = -1, rp = 0;
+    check(rbl_engine_set_net_zero(full.e), "set_net_zero");
+    check(rbl_solver_reset(full.e, 1, &rb, &rp, b.data(), nullptr), "reset");
+    check(rbl_solver_multistep(full.e, -1), "multistep");
+    check(rbl_solver_get(full.e, 0, RBL_GET_AVERAGE, full_strategy.data()), "get");
+  }
+  const int mdp_depth = params.subgame_params.max_depth, fp_iters = params.subgame_params.num_iters;
+  const float mse_net = eval_net_impl(params, ev.e, net_strategy, full_strategy, mdp_depth, fp_iters, /*traverse_by_net=*/true);
+  const float mse_full = eval_net_impl(params, ev.e, net_strategy, full_strategy, mdp_depth, fp_iters, /*traverse_by_net=*/false);
+  return std::make_tuple(exploitability, mse_net, mse_full);
 }
 
 // pybind.cc:86-105 never calls step() on its solver (so it prints the exploitability of the uniform strategy

@@ -17,7 +17,10 @@ What it reproduces:
   * `--print_regret` / `--print_regret_summary` (recursive_eval.cc:28-53): immediate regrets of the list of sampled
     strategies (compute_immediate_regrets, subgame_solving.cc:984-1050 -> rbl_immediate_regrets), CFR runs only, as in
     the reference (:354-357).
-Not reproduced: strategy dumps, oracle-net mode (--repeat_oracle_net, --eval_oracle_values_iters).
+  * `--repeat_oracle_net [--eval_oracle_values_iters N]` (recursive_eval.cc:232, 245-247, 325-334): the value net of the repeated
+    solves is an oracle -- a full-depth solve of every queried subgame (class OracleNet: the rows of a query batch are lanes
+    of one full-depth engine).  Dense mode only.
+Not reproduced: strategy dumps (strategy.*.txt).
 
 `--stream`: the same tool with every full-tree array edge-indexed in HBM (rbl_stream_*, eval_stream.hip) instead of dense
 [N][H][A] host arrays -- the only way to run it at 2 dice x 6 faces (33.5 M nodes: 241 GB dense, 9.7 GB edge-indexed per
@@ -67,12 +70,50 @@ def load_net(eng, path):
     eng.set_net_mlp(*mlp_weights_from_state_dict(sd))
 
 
+class OracleNet:
+    """create_oracle_value_predictor (real_net.cc:89-128; recursive_eval.cc:325-334, `--repeat_oracle_net`): the "value net" is a
+    full-depth solve of the queried subgame -- deserialize_query (subgame_solving.cc:911-929), build_solver(game, state, beliefs,
+    params with max_depth = 100000[, num_iters = --eval_oracle_values_iters]), multistep, get_hand_values(traverser).  The
+    reference solves the rows of a query batch one after the other on the host; here every row of a batch is a LANE of one
+    full-depth engine on the device."""
+
+    def __init__(self, capi, d, f, params, device, max_lanes):
+        self.capi, self.d, self.f, self.params, self.device = capi, d, f, params, device
+        self.eng, self.cap, self.want = None, 0, max_lanes
+        self.A, self.H = 2 * d * f + 1, f ** d
+        self.calls = self.rows = 0
+
+    def __call__(self, q):
+        rows, A, H = q.shape[0], self.A, self.H
+        out = np.zeros((rows, H), np.float32)
+        if self.eng is None:
+            self.cap = max(64, min(self.want, 1 << 14))
+            self.eng = self.capi.Engine(self.d, self.f, self.params, max_lanes=self.cap, device=self.device)
+            self.eng.set_net_zero()
+        self.calls += 1
+        self.rows += rows
+        for r0 in range(0, rows, self.cap):
+            qq = q[r0:r0 + self.cap]
+            n = qq.shape[0]
+            player = (qq[:, 0] + 0.5).astype(np.int32)
+            trav = (qq[:, 1] + 0.5).astype(np.int32)
+            hot = qq[:, 2:2 + A] > 0.5
+            bid = np.where(hot.any(1), A - 1 - np.argmax(hot[:, ::-1], axis=1), -1).astype(np.int32)  # the LAST hot action (:918-922)
+            beliefs = np.stack([qq[:, 2 + A:2 + A + H], qq[:, 2 + A + H:2 + A + 2 * H]], axis=1).astype(np.float64)
+            self.eng.reset(bid, player, beliefs)
+            self.eng.multistep()
+            for i in range(n):
+                out[r0 + i] = self.eng.hand_values(i, int(trav[i]))  # row_values -> float32 tensor (real_net.cc:99)
+        return out
+
+
 def main_stream(a):
     import time
 
     from rebel_amd import capi
 
     assert a.cfr, "--stream: CFR solvers only"
+    assert not a.repeat_oracle_net, "--stream: the oracle net runs in dense mode only"
     d, f = a.num_dice, a.num_faces
     base = solver_params(a)
     t0 = time.perf_counter()
@@ -158,6 +199,10 @@ def main():
     ap.add_argument("--cfr", action="store_true")
     # recursive_eval.cc:248-253: discounted CFR with (alpha, beta, gamma); it switches linear averaging off (:273)
     ap.add_argument("--dcfr", type=float, nargs=3, metavar=("ALPHA", "BETA", "GAMMA"), default=None)
+    # recursive_eval.cc:232, 245-247: the value net of the repeated solves is an ORACLE (a full solve of the queried subgame, with
+    # --eval_oracle_values_iters iterations when given); --net must still be non-empty, as in the reference (:313)
+    ap.add_argument("--repeat_oracle_net", action="store_true")
+    ap.add_argument("--eval_oracle_values_iters", type=int, default=-1)
     ap.add_argument("--print_regret", action="store_true")
     ap.add_argument("--print_regret_summary", action="store_true")
     ap.add_argument("--num_threads", type=int, default=10)  # accepted for command-line compatibility; lanes replace threads
@@ -219,7 +264,14 @@ def main():
         print("##############################################\n##### Recursive solving                      #\n"
               "##############################################")
         eng = capi.Engine(d, f, capi.make_params(max_depth=a.mdp_depth, **base), max_lanes=a.max_lanes, device=a.device)
-        load_net(eng, a.net)
+        if a.repeat_oracle_net:
+            oracle_base = dict(base)
+            if a.eval_oracle_values_iters > 0:
+                oracle_base["num_iters"] = a.eval_oracle_values_iters
+            oracle = OracleNet(capi, d, f, capi.make_params(max_depth=100000, **oracle_base), a.device, a.max_lanes * 64)
+            eng.set_net_callback(oracle)
+        else:
+            load_net(eng, a.net)
         summed = reach_sum = None
         strategy_list = []
 
@@ -248,8 +300,9 @@ def main():
                 ev = capi.ev2(d, f, full_strategy, final, a.device)  # compute_ev2(game, full_strategy, final_strategy), :370
                 print("%5d: %.6f (%.6f,%.6f)\tEV of full: %.6f (%.6f,%.6f)" % (sid + 1, (ex[0] + ex[1]) / 2, ex[0], ex[1],
                                                                           (ev[0] + ev[1]) / 2, ev[0], ev[1]) + regret_report())
-                results.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
-                results_ev.append((f"repeated toleaf {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
+                tag = "repeated oracle toleaf" if a.repeat_oracle_net else "repeated toleaf"  # recursive_eval.cc:377-379
+                results.append((f"{tag} {sid + 1}", "%.6f" % ((ex[0] + ex[1]) / 2)))
+                results_ev.append((f"{tag} {sid + 1}", "%.6f" % ((ev[0] + ev[1]) / 2)))
     for name, val in results[1:]:
         print(f" {name} {val}")
     print("XXX " + json.dumps(dict(results), separators=(", ", ":")))

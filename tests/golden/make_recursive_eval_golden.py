@@ -5,6 +5,7 @@ tool oracle/_ref/recursive_eval (csrc/liars_dice/recursive_eval.cc, built by ora
   (c) --net zero --cfr --print_regret --print_regret_summary   (the regret report of the full-tree section; round 4: made in
       the build container -- it needs no GPU -- and merged into the json: `make_recursive_eval_golden.py --only-regrets`)
   (d) --net zero --cfr --dcfr 1.5 0 2        (round 6, `--only-dcfr`: discounted CFR, made in the build container like (c))
+  (e)-(g) --net zero --repeat_oracle_net [--eval_oracle_values_iters 8] (fictitious play) on 1 die x 3 / 4 faces (round 6, `--only-oracle`)
 on 1 die x 4 faces.  tests/test_eval_parity.py::test_recursive_eval_tool_vs_reference_binary runs scripts/recursive_eval.py
 with the same arguments and compares the XXX / YYY lines (scripts/eval_all.py:100-104 parses them).
 The reference tool loads a TorchScript net on "cuda" first (recursive_eval.cc:316, real_net.cc:130-132), so (b) needs a
@@ -51,6 +52,20 @@ def main():
         golden["zero_dcfr"] = run(COMMON + ["--dcfr", "1.5", "0", "2", "--subgame_iters", "256", "--net", "zero"])
         json.dump(golden, open(path, "w"), indent=1)
         print("\n".join(golden["zero_dcfr"]["stdout"][-8:]))
+        return
+    if "--only-oracle" in sys.argv:  # round 6: cases (e), (f) --repeat_oracle_net [--eval_oracle_values_iters 8] (recursive_eval.cc:
+        # 325-334: the value net is a full solve of the queried subgame; no TorchScript, so no GPU needed), 1 die x 3 faces
+        path = os.path.join(ROOT, "tests", "golden", "recursive_eval_1d4f.json")
+        golden = json.load(open(path))
+        # (fictitious play: with --cfr the reference's oracle trips `sum >= kAlmostZero` in util.h:29 on every game tried)
+        small = ["--num_dice", "1", "--num_faces", "3", "--mdp_depth", "2", "--subgame_iters", "16", "--num_repeats", "2",
+                 "--num_threads", "1", "--net", "zero", "--repeat_oracle_net"]
+        golden["oracle_1d3f"] = run(list(small))
+        golden["oracle_1d3f_iters8"] = run(small + ["--eval_oracle_values_iters", "8"])
+        golden["oracle_1d4f"] = run(small[:3] + ["4"] + small[4:])
+        json.dump(golden, open(path, "w"), indent=1)
+        for k in ("oracle_1d3f", "oracle_1d3f_iters8", "oracle_1d4f"):
+            print(k, golden[k]["xxx"], golden[k]["yyy"])
         return
     out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)

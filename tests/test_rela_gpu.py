@@ -252,7 +252,7 @@ def test_eval_helpers_against_oracle(tmp_path, port):
         ex = port.exploitability2(d, f, strat)
         assert abs(got - (ex[0] + ex[1]) / 2) < 1e-4, (to_leaf, got, ex)
     s = rela.compute_stats_with_net(cfg, path)
-    assert np.isnan(s[1]) and np.isnan(s[2])  # eval_net MSEs are out of scope: NaN, not invented numbers
+    assert np.isfinite(s[1]) and np.isfinite(s[2]) and s[1] > 0 and s[2] > 0  # eval_net MSEs (round 6; golden test below)
 
     # full-tree CFR solve + exploitability (the reference's compute_exploitability_fp never steps; ours does)
     cfg2 = _cfg(rela, 1, 2, 180)
@@ -264,6 +264,45 @@ def test_eval_helpers_against_oracle(tmp_path, port):
         assert rela.compute_exploitability_fp(cfg2) == 0.0
     finally:
         del os.environ["REBEL_AMD_REFERENCE_QUIRKS"]
+
+
+def test_compute_stats_with_net_vs_reference_golden(tmp_path):
+    """rela.compute_stats_with_net (pybind.cc:57-84) all three outputs -- exploitability of the to-leaf recursive strategy and the
+    two eval_net MSEs (stats.cc:44-153: net value vs a full-depth FP solve at the depth-2 / depth-4 public states, beliefs from the
+    net's strategy / from the full-tree solution) -- against the numbers of the UNMODIFIED reference module
+    (tests/golden/stats_with_net.json, made on the GPU box by tests/golden/make_stats_golden.py from oracle/_ref/rela*.so; the
+    MSEs were NaN here through round 5).  Tolerance: the MFMA forward vs torch differs by ~1e-7 per call and the strategies go
+    through 16-32 CFR iterations (P3): 2e-5 absolute on O(0.5) numbers; measured 6e-8."""
+    import json
+    import os
+
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = json.load(open(os.path.join(root, "tests", "golden", "stats_with_net.json")))
+    sd = dict(np.load(os.path.join(root, "tests", "golden", "recursive_eval_net_1d4f.npz")))
+    for name, g in golden.items():
+        d, f = g["num_dice"], g["num_faces"]
+        if name.startswith("1d4f"):
+            net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        else:  # the generator's second net: seed 77, output layer x 30
+            torch.manual_seed(77)
+            net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+            with torch.no_grad():
+                net.output.weight.data *= 30
+                net.output.bias.data *= 30
+        path = str(tmp_path / (name + ".pt"))
+        torch.jit.script(net.eval()).save(path)
+        cfg = _cfg(rela, d, f, g["num_iters"])
+        cfg.subgame_params.use_cfr = g["use_cfr"]
+        got = rela.compute_stats_with_net(cfg, path)
+        print(f"[compute_stats_with_net vs reference] {name}: ours {[float(x) for x in got]} reference {g['reference']}")
+        for k in range(3):
+            assert abs(got[k] - g["reference"][k]) <= 2e-5, (name, k, got, g["reference"])
 
 
 def test_device_replay_ring_equals_host_ring(tmp_path):
