@@ -222,8 +222,7 @@ __global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
   // shapes 0 .. A-1 (root_last_bid + 1); one more key, A, for the root lanes that root de-duplication serves from the
   // representative: their workgroups exit at once, so they sort behind every real tree (launch_sp_order: A + 1 <= 128)
   const int s = threadIdx.x, n_shapes = a.A + (a.dedup ? 1 : 0);
-  // the epoch's representative, recomputed here from the lane shapes (the lowest-indexed root lane, as in sp_scan) rather than
-  // read from sp_scan's lane_skip[]: this kernel then depends on nothing the kernel in front of it wrote
+  // the epoch's representative, recomputed here from the lane shapes (the lowest-indexed root lane, as in sp_scan)
   __shared__ int rep_s;
   if (s == 0) rep_s = 0x7fffffff;
   __syncthreads();
@@ -235,7 +234,16 @@ __global__ void __launch_bounds__(128) sp_order_kernel(const SpArgs a) {
       }
   __syncthreads();
   const int rep = rep_s;
-  auto key = [&](int i) { return a.dedup && a.lane_shape[i] == 0 && i != rep ? a.A : a.lane_shape[i]; };
+  // (Written with the shape in a register and the served key as arithmetic on a register: the first version, `flag ? a.A :
+  // a.lane_shape[i]`, was MISCOMPILED by hipcc 7.2 -- it turned the select into ONE load through a selected pointer (&kernarg.A or
+  // &lane_shape[i]) and lost the condition, so every lane sorted under key A and the launch segments got the LDS request of
+  // whatever lane came first: scripts/micro/scalar_load_after_store.hip rules the memory system out, the ISA shows the select.)
+  const int served_key = n_shapes - 1, dedup = a.dedup;
+  auto key = [&](int i) {
+    const int sh = a.lane_shape[i];
+    const bool served = dedup != 0 && sh == 0 && i != rep;
+    return served ? served_key : sh;
+  };
   for (int p = 0; p < a.n_parts; ++p) {
     const int l0 = a.part_lane[p], l1 = a.part_lane[p + 1];
     int cnt = 0;

@@ -69,6 +69,23 @@ def test_resident_net_kernel_has_no_flat_loads(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+@pytest.mark.parametrize("src", ["selfplay_kernels.hip", "cfr_kernels.hip", "cfr_wave_kernel.hip", "cfr_flat_kernel.hip"])
+def test_parity_kernels_have_no_flat_loads(tmp_path, src):
+    """Round 6: hipcc 7.2 MISCOMPILED `flag ? a.A : a.lane_shape[i]` in sp_order_kernel -- a select between a kernel-argument field
+    and a loaded value became ONE flat load through a selected pointer (&kernarg.A or &lane_shape[i]) and the condition was lost, so
+    every lane sorted under the same key (root de-duplication then sized the 2 dice x 6 faces launch segments by whatever lane came
+    first and hung).  The signature of that code shape is a FLAT load in a kernel whose every pointer is a global one: none may
+    appear in the bit-exact kernels."""
+    out = tmp_path / (src + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I../../include", "-Wno-unused-result", "-ffp-contract=off",
+           "-S", "--cuda-device-only", src, "-o", str(out)]
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    text = out.read_text()
+    assert "s_endpgm" in text and "flat_load" not in text and "flat_store" not in text
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
 def test_wave_cfr_kernel_keeps_four_waves_per_simd_for_the_one_die_games():
     res = _resources("cfr_wave_kernel.hip", ("-ffp-contract=off",))
     by_h = {}
