@@ -521,10 +521,12 @@ def main():
     if world == 1 and not a.no_extra_legs and not a.no_configs and headline == (1, 6, 1024):
         # the other BASELINE.json configurations on this engine, one GPU; short legs (3 warm-up + 5 timed epochs) -- except 2 dice x 6
         # faces, whose root / small-tree mix oscillates for the first epochs of a batch (all lanes start at the root: 2 048, 105,
-        # 1 673, 419, 1 431 ... roots, scripts/probe_2d6f_mix.py) and decides its rate: 8 warm-up + 8 timed epochs there, and every
-        # leg prints its per-epoch root count so that two runs can be compared
+        # 1 673, 419, 1 431 ... roots, scripts/probe_2d6f_mix.py; a damped oscillation that is within +-60 of its level of ~985 after
+        # a dozen epochs) and decides its rate -- a step there is ROUNDS of root workgroups, one per CU, so 1 024 roots are four
+        # rounds and 1 025 five: 16 warm-up + 8 timed epochs there, and every leg prints its per-epoch root count so
+        # that two runs can be compared
         for idx, d_, f_, it_, ln_ in OTHER_CONFIGS:
-            cw, cs = (8, 8) if (d_, f_) == (2, 6) else (min(3, max(1, a.warmup)), min(5, max(2, a.steps)))
+            cw, cs = (16, 8) if (d_, f_) == (2, 6) else (min(3, max(1, a.warmup)), min(5, max(2, a.steps)))
             if a.steps < 3:  # test-sized runs stay short
                 cw, cs = min(cw, 3), min(cs, 2)
             cdt, cunits, cgames, _, cst, _ = run_leg((d_, f_, it_), ln_, cw, cs, 7, False)
