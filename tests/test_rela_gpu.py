@@ -495,6 +495,53 @@ def test_n_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_streams(
     assert all(t >= 2 for t in taken) and sum(2 * sz * t for sz, t in zip(sizes, taken)) == n_add
 
 
+def test_root_dedup_through_the_rela_path_fills_the_replay_with_the_same_rows(monkeypatch):
+    """REBEL_AMD_ROOT_DEDUP=1 is read where the lanes are created, so it works through the drop-in module unchanged: with a frozen
+    net and nobody sampling, the producers fill the ring with whole epochs until the next one does not fit -- the buffer a
+    dedup-on Context leaves behind equals the dedup-off one row for row (the examples are bit-identical; only the work to produce
+    them differs)."""
+    import torch
+
+    import rebel_amd.rela as rela
+    from rebel_amd.models import Net2
+
+    d, f, iters, lanes = 1, 6, 48, 192
+    torch.manual_seed(9)
+    net = Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2)
+    with torch.no_grad():
+        net.output.weight *= 30
+        net.output.bias *= 30
+
+    def fill(dedup):
+        if dedup:
+            monkeypatch.setenv("REBEL_AMD_ROOT_DEDUP", "1")
+        else:
+            monkeypatch.delenv("REBEL_AMD_ROOT_DEDUP", raising=False)
+        model = torch.jit.script(Net2(num_faces=f, num_dice=d, n_hidden=256, use_layer_norm=True, n_layers=2).to("cuda:0")).eval()
+        model.load_state_dict(net.state_dict())
+        locker = rela.ModelLocker([model], "cuda:0")
+        replay = rela.ValuePrioritizedReplay(capacity=4096, seed=3, alpha=1.0, beta=0.4, prefetch=0, use_priority=False,
+                                             compressed_values=False)
+        ctx = rela.Context()
+        cfg = _cfg(rela, d, f, iters)
+        for sd in range(lanes):
+            ctx.push_env_thread(rela.create_cfr_thread(locker, replay, cfg, sd))
+        ctx.start()
+        _wait(lambda: replay.size() >= 5120 - 2 * lanes + 1)  # 1.25 x capacity, less than one more epoch block free
+        time.sleep(0.2)
+        ctx.terminate()
+        _wait(ctx.terminated, 60)
+        q, v, _ = replay.extract()
+        return q.numpy(), v.numpy()
+
+    q0, v0 = fill(False)
+    q1, v1 = fill(True)
+    assert q0.shape == q1.shape and q0.shape[0] == (5120 // (2 * lanes)) * 2 * lanes
+    assert np.array_equal(q0, q1) and np.array_equal(v0, v1)
+    roots = int((q0[0::2, 2:2 + 13].sum(1) == 0).sum())
+    assert lanes < roots < q0.shape[0] // 2  # the first epoch is all roots; later ones a mix: the dedup path really served lanes
+
+
 def test_replay_rings_rehome_and_cross_device_appends():
     """The two branches of the ring's placement logic that a one-GPU box can reach (rela_module.cc ensure_layout / append):
     (a) an EMPTY host ring moves to the GPU with the first device block (re-homing); (b) a host ring that already holds
