@@ -444,27 +444,39 @@ def main():
                                           cfr_gb / HBM_PEAK_GBPS, cfr_gb, net_t * 1e6, cfr_t * 1e6]) if use_dist else None
 
     two_streams = lanes4096 = None
+    leg_errors = {}  # an extra leg that fails must not cost the headline its line: the failure goes INTO the line instead
+
+    def extra_leg(name, *args, **kw):
+        try:
+            return run_leg(*args, **kw)
+        except Exception as ex:
+            leg_errors[name] = repr(ex)
+            return None
+
     parts_env = os.environ.get("RBL_PARTS")
     streams = int(st["n_streams"])  # what the engine ran (rbl_engine_stats), not what the environment suggests
     if world == 1 and not a.no_extra_legs and streams == 1 and not parts_env:
         # what two interleaved half-batches would give at this lane count (kernel tails overlap; per-kernel timings are
         # then contended, which is why the headline leg runs one stream)
         os.environ["RBL_PARTS"] = "2"
-        tdt, tunits, _, _, _, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 0, False)
+        r_ = extra_leg("two_streams", headline, a.lanes, a.warmup, a.steps, 0, False)
         del os.environ["RBL_PARTS"]
-        two_streams = {"value": tunits / tdt, "note": "RBL_PARTS=2, same warm-up and timed epochs as the headline leg"}
+        if r_:
+            two_streams = {"value": r_[1] / r_[0], "note": "RBL_PARTS=2, same warm-up and timed epochs as the headline leg"}
     if world == 1 and not a.no_extra_legs and a.lanes != 4096:
-        ldt, lunits, _, _, _, _ = run_leg(headline, 4096, a.warmup, a.steps, 0, False)
-        lanes4096 = {"value": lunits / ldt, "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
-                     "streams), same warm-up and timed epochs as the headline leg"}
+        r_ = extra_leg("lanes_4096", headline, 4096, a.warmup, a.steps, 0, False)
+        if r_:
+            lanes4096 = {"value": r_[1] / r_[0], "note": "same engine at 4096 lanes (BASELINE config 2's lane count; two "
+                         "streams), same warm-up and timed epochs as the headline leg"}
 
     half_leg = None
     if world == 1 and not a.no_extra_legs:
         # LABELLED EXTRA LEG, never the headline: the same workload with a half model (the trainer's `half_inference`) in the
         # one-product arithmetic a half module selects (rbl_engine_set_net_precision 2: f16 activations x f16 weights, f32
         # accumulation, f32 LayerNorm / GELU -- at least as accurate as the half torch module, tests/test_net_parity.py)
-        hdt, hunits, _, _, hst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False, precision=2)
-        half_leg = (hdt, hunits, hst)
+        r_ = extra_leg("half_inference", headline, a.lanes, a.warmup, a.steps, 7, False, precision=2)
+        if r_:
+            half_leg = (r_[0], r_[1], r_[4])
 
     dedup_leg = None
     if world == 1 and not a.no_extra_legs:
@@ -475,8 +487,9 @@ def main():
         # `value`, `roofline` and `rela_boundary` above keep executing every lane's iterations, as the reference's threads do.
         os.environ["REBEL_AMD_ROOT_DEDUP"] = "1"
         try:
-            ddt, dunits, dgames, dex, dst, _ = run_leg(headline, a.lanes, a.warmup, a.steps, 7, False)
-            dedup_leg = (ddt, dunits, dgames, dex, dst, list(leg_roots))
+            r_ = extra_leg("root_dedup", headline, a.lanes, a.warmup, a.steps, 7, False)
+            if r_:
+                dedup_leg = (r_[0], r_[1], r_[2], r_[3], r_[4], list(leg_roots))
         finally:
             del os.environ["REBEL_AMD_ROOT_DEDUP"]
 
@@ -529,7 +542,10 @@ def main():
             cw, cs = (16, 8) if (d_, f_) == (2, 6) else (min(3, max(1, a.warmup)), min(5, max(2, a.steps)))
             if a.steps < 3:  # test-sized runs stay short
                 cw, cs = min(cw, 3), min(cs, 2)
-            cdt, cunits, cgames, _, cst, _ = run_leg((d_, f_, it_), ln_, cw, cs, 7, False)
+            r_ = extra_leg(f"configs[{idx}]", (d_, f_, it_), ln_, cw, cs, 7, False)
+            if not r_:
+                continue
+            cdt, cunits, cgames, _, cst, _ = r_
             croots = list(leg_roots)
             cnet, ccfr = roofline_blocks((d_, f_, it_), cst, int(cst["n_streams"]))
             keep = ("kernel", "achieved", "unit", "frac", "avg_launch_us", "timed_launches")
@@ -674,6 +690,8 @@ def main():
                     c["speedup_vs_cpu_reference"] = c["value"] / c["cpu_reference"]["value"]
         if configs:
             out["configs"] = configs
+        if leg_errors:
+            out["extra_leg_errors"] = leg_errors
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
