@@ -236,14 +236,26 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     for (int k = tid; k < L; k += NT) {
       const int n = t_leaf[k];
       const int e = opp_edge(n);
-      const double* sg = sig + max(e, 0) * H;
+      // (16-byte reads: a thread walking ITS 288-byte row collides with the threads whose rows are a multiple of 8 away -- 2 304 bytes
+      // = 9 x 64 banks -- and the LDS pipe, not the 36 dependent additions, is what these row-per-thread loops wait for; a b128
+      // read moves twice the bytes per conflicted pass.  Same products, same additions, ascending hands.)
+      const d2* sg2 = reinterpret_cast<const d2*>(sig + max(e, 0) * H);
+      const d2* ro2 = reinterpret_cast<const d2*>(ro);
       double s = 0.0;
       if (e >= 0) {
-#pragma unroll 12
-        for (int h = 0; h < H; ++h) s += ro[h] * sg[h];
+#pragma unroll 6
+        for (int p = 0; p < HP; ++p) {
+          const d2 r = ro2[p], g = sg2[p];
+          s += r[0] * g[0];
+          s += r[1] * g[1];
+        }
       } else {
-#pragma unroll 12
-        for (int h = 0; h < H; ++h) s += ro[h];
+#pragma unroll 6
+        for (int p = 0; p < HP; ++p) {
+          const d2 r = ro2[p];
+          s += r[0];
+          s += r[1];
+        }
       }
       lsum[k] = s;
     }
@@ -267,11 +279,14 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
         const unsigned long long m1 = t_mask[2 * face], m2 = t_mask[2 * face + 1];
         const unsigned long long mine_mask = role == 3 ? ~0ull : (role == 0 ? ~(m1 | m2) : (role == 1 ? m1 : m2));
         double acc = 0.0;
-#pragma unroll 12
-        for (int h = 0; h < H; ++h) {
-          double r = ro[h];
-          if (e >= 0) r = r * sg[h];
-          acc += ((mine_mask >> h) & 1) ? r : 0.0;
+        const d2* sg2 = reinterpret_cast<const d2*>(sg);
+        const d2* ro2 = reinterpret_cast<const d2*>(ro);
+#pragma unroll 6
+        for (int p = 0; p < HP; ++p) {  // (16-byte reads, see the pseudo-leaf loop)
+          d2 r = ro2[p];
+          if (e >= 0) r = r * sg2[p];
+          acc += ((mine_mask >> (2 * p)) & 1) ? r[0] : 0.0;
+          acc += ((mine_mask >> (2 * p + 1)) & 1) ? r[1] : 0.0;
         }
         // the lane that holds role j of this group: reversed thread order, so role j sits at (ln | 3) - j
         double b[NB];
@@ -325,7 +340,89 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // from the net's rows in global memory: twelve children's are requested before the first is used (all 24 at once spilled
     // registers), unconditionally and from a row that exists (a load under a condition is a branch, and loads in different
     // basic blocks are not requested together)
-    if (in_grid) {
+    // Round 6 (fine stamps of root lanes, profiles/r06_cfr_flat_node_values.txt): this pass was 10-12 k cycles on the deepest level
+    // and 7-10 k at the ROOT level of a 62-77 k cycle lane-step, both as chains of LDS round trips:
+    //  * the root level is ONE node with up to 24 children: 18 threads walked them one dependent LDS read (value, and sigma when the
+    //    traverser moves there) at a time while the other 1 006 waited at the barrier.  Now every (child, hand pair) product is formed
+    //    by its own thread into the query-sum scratch (dead until the query phase), and the 18 threads only run the ordered sum over
+    //    operands requested eight at a time: the same products, the same additions in the same order;
+    //  * on the other levels the pseudo-leaves' reach sums (lsum) are requested with the table words, unconditionally, instead of
+    //    inside the per-child branch.
+    const int rc0 = t_cb[n0], rc1 = t_ce[n0];
+    const bool root_fast = n1 - n0 == 1 && !deepest && rc1 > rc0 && (rc1 - rc0) * H <= 4 * L;
+    if (root_fast) {
+      d2* scr_2 = reinterpret_cast<d2*>(qs);
+      if (in_grid)
+        for (int c = rc0 + my_r; c < rc1; c += R) {
+          const d2 v = val_2[(-1 - t_lrow[c]) * HP + h2];  // above the deepest level every child has a value row
+          scr_2[(c - rc0) * HP + h2] = mine ? v * sig_2[(c - 1) * HP + h2] : v;
+        }
+      lds_barrier();
+      if (tid < HP) {
+        const int nc = rc1 - rc0;
+        d2 x = {0.0, 0.0};
+        for (int k0 = 0; k0 < nc; k0 += 8) {
+          d2 pr[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pr[u] = scr_2[min(k0 + u, nc - 1) * HP + tid];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (k0 + u < nc) x += pr[u];
+        }
+        val_2[(-1 - t_lrow[n0]) * HP + tid] = x;
+      }
+    } else if (deepest && 2 * (n1 - n0) <= R) {
+      //  * on the deepest level a node has up to 24 children whose values come from the net's rows in global memory: two batches of
+      //    twelve were two memory round trips, one behind the other, on 432 of the 1 024 threads.  Now TWO thread rows serve a
+      //    node: row A requests children 0..11 and row B children 12..23 at the same time (one round trip); A folds its twelve
+      //    into the node's value row, and behind a barrier B continues the SAME ordered sum from A's partial.  The pseudo-leaves'
+      //    reach sums are requested with the value pairs, sigma (when the traverser moves here) six at a time.
+      constexpr int kC = 12;
+      static_assert(A - 1 <= 2 * kC, "two thread rows of twelve children cover a node");
+      const int nn = n1 - n0;
+      const int half = my_r >= nn ? 1 : 0;
+      const bool act = in_grid && my_r < 2 * nn;
+      const int n = n0 + (act ? my_r - half * nn : 0);
+      const int c0 = t_cb[n], c1 = t_ce[n], cb = c0 + half * kC;
+      const bool work = act && cb < c1;
+      int lr[kC];
+      f2 lvf[kC];
+      double ls[kC];
+#pragma unroll
+      for (int u = 0; u < kC; ++u) lr[u] = t_lrow[max(min(cb + u, c1 - 1), 0)];
+#pragma unroll
+      for (int u = 0; u < kC; ++u) lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
+#pragma unroll
+      for (int u = 0; u < kC; ++u) ls[u] = lsum[max(lr[u], 0)];
+      // the pseudo-leaf values as the floats they are ((double)(float)(net row x reach sum), :257-268): 2 registers per child
+      // instead of the 4 + 2 of (value pair, reach sum) while sigma is gathered
+      f2 vf[kC];
+#pragma unroll
+      for (int u = 0; u < kC; ++u) vf[u] = f2{(float)((double)lvf[u][0] * ls[u]), (float)((double)lvf[u][1] * ls[u])};
+      const int vrow = (-1 - t_lrow[n]) * HP + h2;
+      auto fold = [&](d2 x) {
+#pragma unroll
+        for (int ub = 0; ub < kC; ub += 6) {
+          d2 sg[6];
+          if (mine) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) sg[u] = sig_2[max(min(cb + ub + u, c1 - 1) - 1, 0) * HP + h2];
+          }
+#pragma unroll
+          for (int u = 0; u < 6; ++u)
+            if (cb + ub + u < c1) {  // query_value_net (:257-268) for a pseudo-leaf (as child_val2), else the child's value row
+              const int k = ub + u;
+              const d2 v = lr[k] >= 0 ? d2{(double)vf[k][0], (double)vf[k][1]} : val_2[(-1 - lr[k]) * HP + h2];
+              if (mine) x += v * sg[u];
+              else x += v;
+            }
+        }
+        return x;
+      };
+      if (work && half == 0) val_2[vrow] = fold(d2{0.0, 0.0});
+      lds_barrier();
+      if (work && half == 1) val_2[vrow] = fold(val_2[vrow]);
+    } else if (in_grid) {  // the general form: any level, any workgroup size (twelve children at a time)
       for (int n = n0 + my_r; n < n1; n += R) {
         const int c0 = t_cb[n], c1 = t_ce[n];
         if (c0 == c1) continue;
@@ -333,21 +430,26 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
         d2 x = {0.0, 0.0};
         for (int cb = c0; cb < c1; cb += kC) {
           int lr[kC];
-          f2 lvf[kC];
+          f2 vf[kC];
 #pragma unroll
           for (int u = 0; u < kC; ++u) lr[u] = t_lrow[min(cb + u, c1 - 1)];
-          if (deepest) {  // pseudo-leaves only exist on the last level: above it no child needs the net's rows (the unconditional
-            // loads were two memory round trips for the root's 24 children, whose values are all in LDS)
+          if (deepest) {  // pseudo-leaves only exist on the last level: above it no child needs the net's rows
+            f2 lvf[kC];
+            double ls[kC];
 #pragma unroll
             for (int u = 0; u < kC; ++u) lvf[u] = lvals_2[max(lr[u], 0) * HP + h2];
+#pragma unroll
+            for (int u = 0; u < kC; ++u) ls[u] = lsum[max(lr[u], 0)];
+#pragma unroll
+            for (int u = 0; u < kC; ++u) vf[u] = f2{(float)((double)lvf[u][0] * ls[u]), (float)((double)lvf[u][1] * ls[u])};
           } else {
 #pragma unroll
-            for (int u = 0; u < kC; ++u) lvf[u] = f2{0.f, 0.f};
+            for (int u = 0; u < kC; ++u) vf[u] = f2{0.f, 0.f};
           }
 #pragma unroll
           for (int u = 0; u < kC; ++u)
             if (cb + u < c1) {
-              const d2 v = child_val2(lr[u], lvf[u]);
+              const d2 v = lr[u] >= 0 ? d2{(double)vf[u][0], (double)vf[u][1]} : val_2[(-1 - lr[u]) * HP + h2];
               if (mine) x += v * sig_2[(cb + u - 1) * HP + h2];
               else x += v;
             }
@@ -362,26 +464,35 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     // in one round trip (clamped, unconditional: straight-line code)
     if (in_grid) {
       d2* greg_2 = reinterpret_cast<d2*>(g_reg);
+      // (round 6: the pseudo-leaf's reach sum, the table word and the parent's value row are gathered with the other operands -- they
+      // were read per item behind the previous item's LDS store, three dependent round trips each)
       for (int cb = c_lo + my_r; cb < c_hi; cb += kG * R) {
-        d2 q[kG];
+        d2 q[kG], cv[kG], pv[kG];
         f2 lvf[kG];
-        int lr[kG];
+        int lr[kG], pw[kG];
 #pragma unroll
         for (int u = 0; u < kG; ++u) {
           const int c = min(cb + u * R, c_hi - 1);
           q[u] = greg_2[(c - 1) * HP + h2];
           lr[u] = t_lrow[c];
+          pw[u] = t_pack[c];
           lvf[u] = deepest ? lvals_2[max(lr[u], 0) * HP + h2] : f2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < kG; ++u) {
+          const double ls = lsum[max(lr[u], 0)];
+          const d2 row = val_2[max(-1 - lr[u], 0) * HP + h2];
+          // child_val2: query_value_net (:257-268) for a pseudo-leaf, else the child's value row
+          cv[u] = lr[u] >= 0 ? d2{(double)(float)((double)lvf[u][0] * ls), (double)(float)((double)lvf[u][1] * ls)} : row;
+          pv[u] = val_2[pk_pv(pw[u]) * HP + h2];
         }
 #pragma unroll
         for (int u = 0; u < kG; ++u)
           if (cb + u * R < c_hi) {
-            const int c = cb + u * R;
-            const int e = (c - 1) * HP + h2;
-            const d2 cv = child_val2(lr[u], lvf[u]);
+            const int e = (cb + u * R - 1) * HP + h2;
             d2 qq = q[u];
-            qq += cv;
-            qq -= val_2[pk_pv(t_pack[c]) * HP + h2];
+            qq += cv[u];
+            qq -= pv[u];
             sig_2[e] = d2{qq[0] > kEps ? qq[0] : kEps, qq[1] > kEps ? qq[1] : kEps};
             greg_2[e] = d2{qq[0] * (qq[0] > 0 ? a.pos : a.neg), qq[1] * (qq[1] > 0 ? a.pos : a.neg)};
           }
@@ -494,26 +605,34 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     d2* gsig_2 = reinterpret_cast<d2*>(g_sig);
     const d2* rho_t2 = reinterpret_cast<const d2*>(rho_t);
     if (in_grid) {
+      // gather, compute, scatter (round 6): the table word, sigma and the traverser's reach of every item of the batch are requested
+      // before the first is used -- they sat inside the per-item conditions, one dependent LDS round trip after the other (12 k
+      // cycles of a root lane-step when the traverser owns the 300 depth-1 edges)
       for (int cb = 1 + my_r; cb < N; cb += kG * R) {
-        d2 x[kG];
+        d2 x[kG], sg[kG], rt[kG];
+        int w[kG];
 #pragma unroll
-        for (int u = 0; u < kG; ++u) x[u] = gsum_2[(min(cb + u * R, N - 1) - 1) * HP + h2];  // clamped, unconditional
+        for (int u = 0; u < kG; ++u) {
+          const int c = min(cb + u * R, N - 1);
+          x[u] = gsum_2[(c - 1) * HP + h2];  // clamped, unconditional
+          w[u] = t_pack[c];
+          sg[u] = sig_2[(c - 1) * HP + h2];
+        }
+#pragma unroll
+        for (int u = 0; u < kG; ++u) rt[u] = rho_t2[pk_pr(w[u]) * HP + h2];
 #pragma unroll
         for (int u = 0; u < kG; ++u)
           if (cb + u * R < N) {
-            const int c = cb + u * R;
-            const int e = (c - 1) * HP + h2;
-            const int w = t_pack[c];
-            const d2 s = sig_2[e];
-            if ((root_player ^ pk_pdp(w)) == t) {
+            const int e = (cb + u * R - 1) * HP + h2;
+            if ((root_player ^ pk_pdp(w[u])) == t) {
               d2 xx = x[u];
               xx *= a.strat;
-              xx += rho_t2[pk_pr(w) * HP + h2] * s;
+              xx += rt[u] * sg[u];
               gsum_2[e] = xx;
-              gsig_2[e] = s;
+              gsig_2[e] = sg[u];
             }
-            if (snap_now) snap_2[e] = s;
-            if (rep) snap_all_2[e] = s;
+            if (snap_now) snap_2[e] = sg[u];
+            if (rep) snap_all_2[e] = sg[u];
           }
       }
     }
@@ -532,10 +651,19 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       const double* rn = (pm == 0 ? rho1 : rho0) + pr * H;
       const double* sg = sig + (n - 1) * H;
       double sm = 0, sn = 0;
-#pragma unroll 12
-      for (int h = 0; h < H; ++h) sm += rm[h] * sg[h] + kEps;
-#pragma unroll 12
-      for (int h = 0; h < H; ++h) sn += rn[h] + kEps;
+      const d2 *rm2 = reinterpret_cast<const d2*>(rm), *rn2 = reinterpret_cast<const d2*>(rn), *sg2 = reinterpret_cast<const d2*>(sg);
+#pragma unroll 6
+      for (int p = 0; p < HP; ++p) {  // (16-byte reads, see the leaf sums of the reach phase)
+        const d2 r = rm2[p], g = sg2[p];
+        sm += r[0] * g[0] + kEps;
+        sm += r[1] * g[1] + kEps;
+      }
+#pragma unroll 6
+      for (int p = 0; p < HP; ++p) {
+        const d2 r = rn2[p];
+        sn += r[0] + kEps;
+        sn += r[1] + kEps;
+      }
       double y = __builtin_amdgcn_rcp(sm);
       double er = __builtin_fma(-sm, y, 1.0);
       y = __builtin_fma(y, er, y);
