@@ -115,6 +115,8 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
     ++dbg_k;                                                           \
   } while (0)
   RBL_STAMP();  // 0: start
+  if (dbg && threadIdx.x == 0)  // where this workgroup runs (HW_ID | XCC_ID << 32): lets a probe line the workgroups of a CU up in time
+    dbg[15] = (long long)(unsigned)__builtin_amdgcn_s_getreg(63492) | ((long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32);
 #if defined(RBL_FINE) && RBL_FINE == 1
 #define RBL_F1() RBL_STAMP()
 #else
@@ -475,8 +477,8 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
           const int c = min(cb + u * R, c_hi - 1);
           q[u] = greg_2[(c - 1) * HP + h2];
           lr[u] = t_lrow[c];
-          pw[u] = t_pack[c];
           lvf[u] = deepest ? lvals_2[max(lr[u], 0) * HP + h2] : f2{0.f, 0.f};
+          pw[u] = t_pack[c];
         }
 #pragma unroll
         for (int u = 0; u < kG; ++u) {
@@ -561,6 +563,15 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
   }
   RBL_STAMP();  // 5: bottom-up
 
+  // the write-back's strategy sums are requested HERE, two phases early (round 6): their memory round trip runs under the root
+  // mean, the barrier and the new-reach pass instead of at the head of the write-back (where it was 3-4 k exposed cycles of a
+  // root lane-step; a lane of up to 6 x R + 1 nodes needs this one batch only)
+  d2 wb_x[kG];
+  {
+    const d2* gsum_2 = reinterpret_cast<const d2*>(g_sum);
+#pragma unroll
+    for (int u = 0; u < kG; ++u) wb_x[u] = gsum_2[(min(1 + my_r + u * R, N - 1) - 1) * HP + h2];  // clamped, unconditional
+  }
   // ---------------------------------------------------------------- running mean of the root values (:579-590)
   if (tid < H) {
     double m = rmean_t;
@@ -611,10 +622,12 @@ __global__ void __launch_bounds__(kFlatMaxThreads) cfr_flat_kernel(const CfrArgs
       for (int cb = 1 + my_r; cb < N; cb += kG * R) {
         d2 x[kG], sg[kG], rt[kG];
         int w[kG];
+        const bool first = cb == 1 + my_r;  // the first batch was requested before the new-reach pass (wb_x)
 #pragma unroll
         for (int u = 0; u < kG; ++u) {
           const int c = min(cb + u * R, N - 1);
-          x[u] = gsum_2[(c - 1) * HP + h2];  // clamped, unconditional
+          if (first) x[u] = wb_x[u];
+          else x[u] = gsum_2[(c - 1) * HP + h2];  // clamped, unconditional
           w[u] = t_pack[c];
           sg[u] = sig_2[(c - 1) * HP + h2];
         }
