@@ -44,14 +44,35 @@ struct Row {
 template <int H>
 __device__ __forceinline__ Row<H> load_row(const double* p) {
   Row<H> r;
+  if constexpr (H % 2 == 0) {
+    // every row of the LDS image starts at a multiple of 8 H bytes from a 16-byte aligned base: with an even H a thread reads its
+    // row in 16-byte pieces (round 6: a wave's ds_read_b64 of rows 8 H bytes apart is a 2-way bank conflict at H = 6, its
+    // ds_read_b128 none -- the lesson of the 2 dice x 6 faces kernel, profiles/r06_cfr_flat_node_values.txt)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* p2 = reinterpret_cast<const d2*>(p);
 #pragma unroll
-  for (int h = 0; h < H; ++h) r.v[h] = p[h];
+    for (int h = 0; h < H / 2; ++h) {
+      const d2 v = p2[h];
+      r.v[2 * h] = v[0];
+      r.v[2 * h + 1] = v[1];
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) r.v[h] = p[h];
+  }
   return r;
 }
 template <int H>
 __device__ __forceinline__ void store_row(double* p, const Row<H>& r) {
+  if constexpr (H % 2 == 0) {  // 16-byte pieces, as load_row
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2* p2 = reinterpret_cast<d2*>(p);
 #pragma unroll
-  for (int h = 0; h < H; ++h) p[h] = r.v[h];
+    for (int h = 0; h < H / 2; ++h) p2[h] = d2{r.v[2 * h], r.v[2 * h + 1]};
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) p[h] = r.v[h];
+  }
 }
 
 // orders this wave's LDS / global accesses across a phase boundary: the LDS pipeline serves a wave's requests in
