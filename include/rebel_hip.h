@@ -250,7 +250,9 @@ int64_t rbl_selfplay_games_finished(rbl_selfplay* sp);
  * (recursive_solving.cc:160-163) and CFR::step draws nothing, so every lane that is in its root subgame in an epoch computes the
  * same num_iters iterations.  With the option on, one lane per epoch solves the root subgame and the other root lanes sample from
  * its strategy at THEIR act_iteration: trajectories and training examples stay bit-identical per seed, rbl_selfplay_advance then
- * returns the iterations actually EXECUTED, and this call returns the lane-epochs served that way so far (0 when off). */
+ * returns the iterations actually EXECUTED, and this call returns the lane-epochs served that way so far (0 when off).
+ * (The per-lane solver arrays of a served lane -- rbl_solver_get on the engine underneath -- are NOT maintained in such an epoch:
+ * only what the reference's data path observes is, the examples and the next public state.) */
 int64_t rbl_selfplay_root_dedup_served(rbl_selfplay* sp);
 /* per-lane public state for inspection: last_bid, player_id (liars_dice.h:35-44) */
 int rbl_selfplay_state(rbl_selfplay* sp, int lane, int32_t* last_bid, int32_t* player_id);
