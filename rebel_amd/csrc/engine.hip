@@ -500,7 +500,12 @@ void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, h
         launch_split_queries(q_dev, g_.A, g_.H, d_tmp_dyn_.p, q_ds_, d_tmp_stat_.p, q_ss_, rows, st);
         MlpDev m2 = mlp_;
         m2.q_stat = d_tmp_stat_.p;
+        if (net_grid_env_ >= 0) m2.grid_cap = net_grid_env_;  // developer override (RBL_NET_GRID): standalone forwards too
         launch_mlp_forward(m2, d_tmp_dyn_.p, rows, out_dev, st, nullptr);
+      } else if (net_grid_env_ >= 0) {
+        MlpDev m2 = mlp_;
+        m2.grid_cap = net_grid_env_;
+        launch_mlp_forward(m2, q_dev, rows, out_dev, st, range);
       } else {
         launch_mlp_forward(mlp_, q_dev, rows, out_dev, st, range);
       }

@@ -3,7 +3,8 @@
 2 048-lane part: wall time per launch on device buffers (standalone entry point: split-layout conversion kernel + forward) with the
 grid capped at 192 workgroups (what the engine gives the net kernel when two small parts interleave) and uncapped, and the
 RBL_NET_DBG stamps of the workgroups: cycles of the FIRST group (cold start: weights into registers / LDS, first rows' round trip)
-and per group over the whole workgroup.  usage: probe_net_small_batches.py [dice faces]"""
+and per group over the whole workgroup.  A third argument "fine" sweeps 1.75 ... 3.5 groups per workgroup in small steps (where
+the cost of a partial last round shows).  usage: probe_net_small_batches.py [dice faces [fine]]"""
 import os
 import sys
 import time
@@ -27,7 +28,9 @@ for cap in (192, 0):
     grid = cap or 256
     print(f"== {dice}d x {faces}f, grid cap {grid} workgroups (64-row groups, one persistent workgroup per CU)")
     print("  groups  per-WG  rows     us/launch   first group (cycles)  cycles/group over the workgroup   workgroup total")
-    for per_wg in (0.5, 1.0, 1.8, 2.0, 2.46, 3.0, 4.0, 8.0, 36.0):
+    fine = len(sys.argv) > 3 and sys.argv[3] == "fine"
+    sweep = (1.75, 2.0, 2.1, 2.25, 2.46, 2.6, 2.75, 2.9, 3.0, 3.1, 3.25, 3.5) if fine else (0.5, 1.0, 1.8, 2.0, 2.46, 3.0, 4.0, 8.0, 36.0)
+    for per_wg in sweep:
         groups = max(1, int(round(per_wg * grid)))
         rows = groups * 64
         rng = np.random.default_rng(1)
