@@ -479,19 +479,39 @@ def test_n_lockers_one_replay_homed_by_env_contents_equal_the_lanes_own_streams(
             yield eq, ev
 
     gens = [stream(s_) for s_ in seeds]
-    nxt = [next(g) for g in gens]
-    pos, taken = 0, [0] * n_lockers
-    while pos < q.shape[0]:
+    epochs = [[] for _ in range(n_lockers)]  # worker k's epoch blocks, generated on demand
+
+    def epoch(k, i):
+        while len(epochs[k]) <= i:
+            epochs[k].append(next(gens[k]))
+        return epochs[k][i]
+
+    # Every lane's FIRST epoch is the root subgame with uniform beliefs: its two examples do not depend on the seed, so the
+    # workers' first blocks are runs of the same row pair and a greedy left-to-right assignment can give a long block's rows to
+    # shorter ones and then be stuck (seen once a fast worker publishes its second epoch before a slow one's first).  Search over
+    # the assignments instead: a state is how many epochs of each worker have been consumed (which fixes the row position).
+    rows_of = [2 * sz for sz in sizes]
+    stack, seen, taken, deepest = [tuple([0] * n_lockers)], set(), None, (-1, ())
+    while stack:
+        st = stack.pop()
+        if st in seen:
+            continue
+        seen.add(st)
+        pos = sum(r * t for r, t in zip(rows_of, st))
+        if pos == q.shape[0]:
+            taken = list(st)
+            break
+        if pos > deepest[0]:
+            deepest = (pos, st)
         for k in range(n_lockers):
-            eq, ev = nxt[k]
-            n = eq.shape[0]
-            if pos + n <= q.shape[0] and np.array_equal(q[pos:pos + n], eq) and np.array_equal(v[pos:pos + n], ev):
-                pos += n
-                taken[k] += 1
-                nxt[k] = next(gens[k])
-                break
-        else:
-            raise AssertionError(f"row {pos}: the buffer continues with no worker's next epoch (epochs taken: {taken})")
+            n = rows_of[k]
+            if pos + n > q.shape[0]:
+                continue
+            eq, ev = epoch(k, st[k])
+            assert eq.shape[0] == n
+            if np.array_equal(q[pos:pos + n], eq) and np.array_equal(v[pos:pos + n], ev):
+                stack.append(st[:k] + (st[k] + 1,) + st[k + 1:])
+    assert taken is not None, f"the buffer is no interleaving of the workers' epoch streams (deepest match: row {deepest[0]}, epochs {deepest[1]})"
     assert all(t >= 2 for t in taken) and sum(2 * sz * t for sz, t in zip(sizes, taken)) == n_add
 
 
