@@ -128,7 +128,6 @@ class Engine {
   const int* depth_dev() const { return d_depth_.p; }
   bool device_epochs_supported() const { return net_mode_ != NetMode::kCallback; }
   int parts_for(int B) const;                                    // lane parts (= streams) a batch of B lanes is split into
-  int net_tail_items(int B) const;                               // 1: 32-row items in the last round of the persistent forward
   int net_grid_cap(int B) const;                                 // persistent net workgroups for a batch of B lanes (0 = one per CU)
   void part_lanes(int B, int* part_lane /*[kSpMaxParts+1]*/) const;
   void begin_epoch_device(int B, const SpEpochInfo* info_dev);   // descriptors already enqueued on stream(); solver init
@@ -242,7 +241,7 @@ class Engine {
   size_t rows_lds_bytes_ = 0;
   bool wave_ok_ = false;  // kModeStep runs on cfr_wave_kernel (one wavefront per lane)
   size_t wave_lds_bytes_ = 0;
-  int n_cus_ = 256, net_grid_env_ = -1, net_tail_env_ = -1;  // CUs of the device; RBL_NET_GRID (-1: automatic)
+  int n_cus_ = 256, net_grid_env_ = -1;  // CUs of the device; RBL_NET_GRID (-1: automatic)
   bool rows_global_ok_ = false;  // big games: row kernel with sigma / regrets in place in global memory
   size_t rows_global_lds_ = 0;
   int flat_threads_ = 1024;

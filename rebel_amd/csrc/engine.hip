@@ -281,7 +281,6 @@ void Engine::construct() {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && v > 0) n_cus_ = v;
     net_grid_env_ = env_int("RBL_NET_GRID", -1);
-    net_tail_env_ = env_int("RBL_NET_TAIL", -1);
   }
   flat_threads_ = std::min(1024, std::max(64, env_int("RBL_CFR_FLAT_THREADS", 1024) / 64 * 64));
   use_order_ = rows_global_ok_ && env_int("RBL_GS_SORT", 1) != 0;
@@ -501,13 +500,11 @@ void Engine::net_forward_dev(const float* q_dev, int64_t rows, float* out_dev, h
         launch_split_queries(q_dev, g_.A, g_.H, d_tmp_dyn_.p, q_ds_, d_tmp_stat_.p, q_ss_, rows, st);
         MlpDev m2 = mlp_;
         m2.q_stat = d_tmp_stat_.p;
-        if (net_grid_env_ >= 0) m2.grid_cap = net_grid_env_;  // developer overrides (RBL_NET_GRID, RBL_NET_TAIL): standalone forwards too
-        if (net_tail_env_ >= 0) m2.tail_items = net_tail_env_ ? 1 : 0;
+        if (net_grid_env_ >= 0) m2.grid_cap = net_grid_env_;  // developer override (RBL_NET_GRID): standalone forwards too
         launch_mlp_forward(m2, d_tmp_dyn_.p, rows, out_dev, st, nullptr);
-      } else if (net_grid_env_ >= 0 || net_tail_env_ >= 0) {
+      } else if (net_grid_env_ >= 0) {
         MlpDev m2 = mlp_;
-        if (net_grid_env_ >= 0) m2.grid_cap = net_grid_env_;
-        if (net_tail_env_ >= 0) m2.tail_items = net_tail_env_ ? 1 : 0;
+        m2.grid_cap = net_grid_env_;
         launch_mlp_forward(m2, q_dev, rows, out_dev, st, range);
       } else {
         launch_mlp_forward(mlp_, q_dev, rows, out_dev, st, range);
@@ -737,15 +734,6 @@ int Engine::net_grid_cap(int B) const {
   if (net_grid_env_ >= 0) return net_grid_env_;
   const int n = parts_for(B);
   return n >= 2 && wave_ok_ && B / n <= 2048 ? n_cus_ * 3 / 4 : 0;
-}
-
-// The same small interleaved parts are the launches of two to six ROUNDS of 64-row groups, where a last round that is mostly empty
-// costs as much as a full one (profiles/r06_net_small_batches.txt): there the persistent forward runs the last round's groups as
-// 32-row items on two workgroups each (MlpDev::tail_items).  RBL_NET_TAIL=0/1 overrides.
-int Engine::net_tail_items(int B) const {
-  if (net_tail_env_ >= 0) return net_tail_env_ ? 1 : 0;
-  const int n = parts_for(B);
-  return n >= 2 && wave_ok_ && B / n <= 2048 ? 1 : 0;
 }
 
 int Engine::parts_for(int B) const {
@@ -1030,7 +1018,6 @@ void Engine::run_net() {
   // net_mutex_, so that a weight refresh on another thread (set_net_mlp rebuilds mlp_) never races with it
   MlpDev mlp = mlp_;
   mlp.grid_cap = net_grid_cap(B_);
-  mlp.tail_items = net_tail_items(B_);
   TimingAbortGuard abort_open_sample_on_unwind{this};
   for (int part = 0; part < n_parts_; ++part) {
     if (only_part_ >= 0 && part != only_part_) continue;

@@ -36,9 +36,6 @@ struct MlpDev {
   // tile 5: at most this many persistent workgroups (0 = one per CU).  The engine leaves a quarter of the CUs to the OTHER lane
   // part's CFR kernel when two small parts interleave on two streams (engine.hip: net_grid_cap)
   int grid_cap = 0;
-  // tile 5: 1 = when the last round's groups fit on half of the workgroups, run them as 32-row items on two workgroups each
-  // (net_resident_kernel.hip TAIL; built for one output tile, one hidden layer, one or two input chunks -- ignored elsewhere)
-  int tail_items = 0;
 };
 
 // Host-side packing: returns one float blob plus the offsets of the members above (in floats).

@@ -147,26 +147,25 @@ __device__ __forceinline__ f32x4 ko_mfma(f16x8 a, f16x8 b, f32x4 c) {
 // activations are rounded to f16, the weights keep 22 bits; 1 = x_h W_h: activations and weights rounded to f16, f32
 // accumulation (the reference's half_inference, cfvpy/selfplay.py:42-43, with fewer roundings than a half torch module).
 // With PROD < 3 the lo fragments of the X image are neither written nor read.
-// RT: row tiles multiplied (kRT; 2 for a 32-row tail item -- the image keeps its kRT-tile layout, tiles RT.. are not touched)
-template <int NRES, int NTAIL, int NT1, int PF, int PROD, int RT = kRT>
+template <int NRES, int NTAIL, int NT1, int PF, int PROD>
 __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW],
                                               const Frag (&th)[NT1][kOTW], const Frag (&tl)[NT1][kOTW],
                                               const f32x4* __restrict__ X, int lane, f32x4 (&acc)[kOTW][kRT]) {
   constexpr int NKS = NRES + NTAIL;
-  constexpr int NS = NKS * RT;
+  constexpr int NS = NKS * kRT;
   Frag xb[PF + 1][2];
 #pragma unroll
   for (int s = 0; s < PF && s < NS; ++s) {
-    xb[s][0].v = X[(((s / RT) * 2 + 0) * kRT + (s % RT)) * 64 + lane];
-    if (PROD == 3) xb[s][1].v = X[(((s / RT) * 2 + 1) * kRT + (s % RT)) * 64 + lane];
+    xb[s][0].v = X[(((s / kRT) * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
+    if (PROD == 3) xb[s][1].v = X[(((s / kRT) * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int ks = s / RT, rt = s % RT, slot = s % (PF + 1);
+    const int ks = s / kRT, rt = s % kRT, slot = s % (PF + 1);
     if (s + PF < NS) {
       const int n = s + PF, nslot = n % (PF + 1);
-      xb[nslot][0].v = X[(((n / RT) * 2 + 0) * kRT + (n % RT)) * 64 + lane];
-      if (PROD == 3) xb[nslot][1].v = X[(((n / RT) * 2 + 1) * kRT + (n % RT)) * 64 + lane];
+      xb[nslot][0].v = X[(((n / kRT) * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
+      if (PROD == 3) xb[nslot][1].v = X[(((n / kRT) * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
 #ifdef RBL_SPLIT_KS
@@ -200,28 +199,28 @@ __device__ __forceinline__ void gemm_resident(const Frag (&wh)[NRES][kOTW], cons
 // and are there; once they have been used, `fetch_late` requests the remaining ones INTO THE SAME REGISTERS, and the resident
 // k-steps (>= 16 steps of matrix work per wave) cover that round trip.  Streamed weights so never hold more than NEARLY k-steps
 // of registers (2 x 16 VGPRs instead of up to 64: what hipcc could not fit and spilled from the resident set).
-template <int NRES, int NTAIL, int NEARLY, int NE1, int PF, int PROD, int RT, class FetchLate>
+template <int NRES, int NTAIL, int NEARLY, int NE1, int PF, int PROD, class FetchLate>
 __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const Frag (&wl)[NRES][kOTW], Frag (&th)[NE1][kOTW],
                                             Frag (&tl)[NE1][kOTW], const f32x4* __restrict__ X, int lane,
                                             f32x4 (&acc)[kOTW][kRT], FetchLate&& fetch_late) {
   static_assert(NTAIL - NEARLY <= NEARLY, "late k-steps reuse the early ones' registers");
-  constexpr int NKS = NRES + NTAIL, NS = NKS * RT;
+  constexpr int NKS = NRES + NTAIL, NS = NKS * kRT;
   // position in the multiplication order -> k-step of the X image
   auto ks_of = [](int p) { return p < NEARLY ? NRES + p : (p < NEARLY + NRES ? p - NEARLY : p); };
   Frag xb[PF + 1][2];
 #pragma unroll
   for (int s = 0; s < PF && s < NS; ++s) {
-    const int k = ks_of(s / RT);
-    xb[s][0].v = X[((k * 2 + 0) * kRT + (s % RT)) * 64 + lane];
-    if (PROD == 3) xb[s][1].v = X[((k * 2 + 1) * kRT + (s % RT)) * 64 + lane];
+    const int k = ks_of(s / kRT);
+    xb[s][0].v = X[((k * 2 + 0) * kRT + (s % kRT)) * 64 + lane];
+    if (PROD == 3) xb[s][1].v = X[((k * 2 + 1) * kRT + (s % kRT)) * 64 + lane];
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int p = s / RT, rt = s % RT, slot = s % (PF + 1);
+    const int p = s / kRT, rt = s % kRT, slot = s % (PF + 1);
     if (s + PF < NS) {
-      const int n = s + PF, nslot = n % (PF + 1), k = ks_of(n / RT);
-      xb[nslot][0].v = X[((k * 2 + 0) * kRT + (n % RT)) * 64 + lane];
-      if (PROD == 3) xb[nslot][1].v = X[((k * 2 + 1) * kRT + (n % RT)) * 64 + lane];
+      const int n = s + PF, nslot = n % (PF + 1), k = ks_of(n / kRT);
+      xb[nslot][0].v = X[((k * 2 + 0) * kRT + (n % kRT)) * 64 + lane];
+      if (PROD == 3) xb[nslot][1].v = X[((k * 2 + 1) * kRT + (n % kRT)) * 64 + lane];
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool res = p >= NEARLY && p < NEARLY + NRES;
@@ -241,7 +240,7 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
     for (int ot = 0; ot < kOTW; ++ot)
       acc[ot][rt] = RBL_MFMA(res ? wh[kr][ot].h : th[kt][ot].h, xb[slot][0].h, acc[ot][rt]);
     __builtin_amdgcn_sched_barrier(0);
-    if (NTAIL > NEARLY && s == NEARLY * RT - 1) {
+    if (NTAIL > NEARLY && s == NEARLY * kRT - 1) {
       fetch_late();
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -261,11 +260,7 @@ __device__ __forceinline__ void gemm_hidden(const Frag (&wh)[NRES][kOTW], const 
 // the four resident k-steps.  (First built as "first layer resident, second through a ring of 2-3 k-step slots": 256 KB per CU
 // had to arrive inside ONE 4 k-cycle GEMM phase -- exactly the 64 B/clk of the L2 -> CU path -- and that GEMM took 9 k cycles
 // whatever the ring depth; split over both GEMMs and both epilogues the same bytes have 4x the time.)
-// TAIL (round 6, small batches): a launch is whole ROUNDS of 64-row groups (profiles/r06_net_small_batches.txt: 2.1 groups per
-// workgroup cost what 3.0 do).  With TAIL, when the groups of the last round fit on half of the workgroups, each of them is
-// processed as TWO 32-row items by two workgroups (2 row tiles: half the MFMAs and half the epilogue per barrier), so the last
-// round ends after a half item's time.  The engine asks for it where the grid cap applies (two small interleaved lane parts).
-template <int K0C, bool LN, int NOTV, int PROD, int NH, bool TAIL = false>
+template <int K0C, bool LN, int NOTV, int PROD, int NH>
 __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpDev m, const float* __restrict__ queries,
                                                                     int64_t rows, float* __restrict__ out, int n_groups,
                                                                     const long long* __restrict__ range) {
@@ -279,23 +274,6 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     rows = r1 - r0;
     n_groups = (int)((rows + kRows - 1) / kRows);
   }
-  // work items: item i < half_from is the 64-row group i; the items from half_from on are the 32-row halves of the last
-  // round's groups, in row order (at most one per workgroup, and it is that workgroup's last item)
-  int n_items = n_groups, half_from = n_groups;
-  if constexpr (TAIL) {
-    static_assert(NOTV == 1, "32-row tail items are built for one output tile");
-    if (n_groups > 0) {
-      const int W = (int)gridDim.x, full = ((n_groups - 1) / W) * W, r = n_groups - full;
-      if (2 * r <= W) {
-        half_from = full;
-        n_items = full + 2 * r;
-      }
-    }
-  }
-  auto item_row0 = [&](int it) -> int64_t {
-    if (!TAIL || it < half_from) return (int64_t)it * kRows;
-    return (int64_t)(half_from + ((it - half_from) >> 1)) * kRows + ((it - half_from) & 1) * (kRows / 2);
-  };
   constexpr int kParamFloats = (NH + 1) * 3 * 256 + 64;  // per layer: bias, gamma, beta / sqrt2; then the output bias
   constexpr int kOutBias = (NH + 1) * 3 * 256;
   constexpr int kWoF4 = kKS * 2 * 64;             // one output tile's weight fragments (16 KB)
@@ -435,10 +413,9 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // row cover it in 16-byte pieces).  The loads for group n+1 are issued right after group n is staged and stay in
   // flight until the next staging step.
   float qn[K0C][4];
-  auto fetch_queries = [&](int it) {
-    const int64_t row = item_row0(it) + (wave >> 1) * 16 + j;
-    // (the row tiles 2, 3 of a 32-row item belong to its sibling: zeros are staged there and never multiplied)
-    const bool ok = it < n_items && row < rows && (!TAIL || it < half_from || (wave >> 1) < kRT / 2);
+  auto fetch_queries = [&](int grp) {
+    const int64_t row = (int64_t)grp * kRows + (wave >> 1) * 16 + j;
+    const bool ok = grp < n_groups && row < rows;
     if (q_stat) {  // split layout: the virtual row is (dynamic row | static row), both strides multiples of 4 floats, so a
       // thread's four consecutive inputs are one aligned 16-byte load from one of the two
       const int DS = m.q_dyn_stride, SS = m.q_stat_stride;
@@ -478,14 +455,13 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // extra live address at the head of the GEMM pushed hipcc into scratch spills (20 bytes per lane), so there the bias is
   // added in the epilogue as before
   constexpr bool kBiasInAcc = K0C <= 2;
-  auto init_acc = [&](auto rt_tag, const float* pl) {
-    constexpr int RT = decltype(rt_tag)::value;
+  auto init_acc = [&](const float* pl) {
 #pragma unroll
     for (int ot = 0; ot < kOTW; ++ot) {
       f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (kBiasInAcc) b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) acc[ot][rt] = b4;
+      for (int rt = 0; rt < kRT; ++rt) acc[ot][rt] = b4;
     }
   };
 
@@ -495,8 +471,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
   // that layer's weights are packed with k running as (tile, g, r) inside the k-step -- which is what pack_mlp does for
   // tile 5.  So there is no f32 image and no transposition: the only thing the waves exchange per layer is the row
   // variance (one float per row and wave).  The first barrier doubles as "everybody is done reading the old X".
-  auto epilogue_regs = [&](auto rt_tag, auto last_tag, float inv_s, const float* pl) {
-    constexpr int RT = decltype(rt_tag)::value;        // row tiles of this item (kRT; 2 for a 32-row tail item)
+  auto epilogue_regs = [&](auto last_tag, float inv_s, const float* pl) {
     constexpr bool kLast = decltype(last_tag)::value;  // feeds the output layer: tile 0 straight from registers
     // output layer, k-step `wave` of the first NOT tiles: 2 KB per tile from L2 per wave and group, requested here, used at
     // the end
@@ -523,7 +498,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       for (int ot = 0; ot < kOTW; ++ot) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(pl + 32 * wave + 16 * ot + 4 * g);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) d[ot][rt] = acc[ot][rt] * inv_s + b4;
+        for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = acc[ot][rt] * inv_s + b4;
       }
     }
     constexpr float kC = 0.70710678118654752440f;
@@ -546,16 +521,14 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 #pragma unroll
       for (int ot = 0; ot < kOTW; ++ot)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) d[ot][rt] = d[ot][rt] * g4[ot];
+        for (int rt = 0; rt < kRT; ++rt) d[ot][rt] = d[ot][rt] * g4[ot];
     };
     if constexpr (kGammaEarly) fetch_gamma_beta();
     if constexpr (LN) {
       // weights and biases are centred over the output features on the host: d has zero row mean, only the variance is left
       float q[kRT];
 #pragma unroll
-      for (int rt = RT; rt < kRT; ++rt) q[rt] = 0.f;  // (rows of the sibling item: their factor is computed and not used)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
+      for (int rt = 0; rt < kRT; ++rt) {
         f32x2 q2 = splat2(0.f);
 #pragma unroll
         for (int ot = 0; ot < kOTW; ++ot) {
@@ -607,7 +580,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     }
     if constexpr (!kGammaEarly) fetch_gamma_beta();
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
+    for (int rt = 0; rt < kRT; ++rt) {
       f16x2 h[4], l[4];
 #pragma unroll
       for (int ot = 0; ot < kOTW; ++ot)
@@ -702,10 +675,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
 
   const int stamp_group = m.stagger;  // developer aid (RBL_MLP_STAGGER): which of the workgroup's groups the stamps describe
   int group_no = 0;
-  // one work item: a 64-row group (RT = kRT row tiles) or, with TAIL, a 32-row half of one (RT = 2)
-  auto run_item = [&](auto rt_tag, const int grp) __attribute__((always_inline)) {
-    constexpr int RT = decltype(rt_tag)::value;
-    const int64_t row0 = item_row0(grp);
+  for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x, ++group_no) {
+    const int64_t row0 = (int64_t)grp * kRows;
     dbg = group_no == stamp_group ? dbg_end : nullptr;  // (0: the first group, which includes the cold start)
     dbg_k = 0;
     // lane-derived indices are re-derived every group: hoisted out of the loop, the dozens of LDS / global addresses built
@@ -742,8 +713,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     RBL_NSTAMP();  // 1: staged
 
     // -------------------------------------------------------------- layer 0
-    init_acc(rt_tag, prm);
-    gemm_resident<K0C, 0, K0C, kPF, PROD, RT>(th, tl, th, tl, Xq, lane, acc);
+    init_acc(prm);
+    gemm_resident<K0C, 0, K0C, kPF, PROD>(th, tl, th, tl, Xq, lane, acc);
     RBL_NSTAMP();  // 2: L0 gemm
     // The streamed k-steps of the hidden layer take over registers of the layer-0 weights (dead from here on): the first kEarly
     // of them are requested BEFORE the layer-0 epilogue, whose ~6 k cycles cover the L2 round trips; the rest is requested
@@ -768,23 +739,23 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     using IT = std::integral_constant<int, kTail>;
     fetch_tail(wt, I0{}, IE{}, I0{});
     RBL_NSTAMP();  // 3
-    epilogue_regs(rt_tag, std::false_type{}, m.inv_scale[0], prm);
+    epilogue_regs(std::false_type{}, m.inv_scale[0], prm);
     RBL_NSTAMP();  // 4: L0 epilogue
 
     // -------------------------------------------------------------- hidden layer, weights from registers
-    init_acc(rt_tag, prm + 768);
+    init_acc(prm + 768);
     if constexpr (kTail == 0)
-      gemm_resident<kRes, 0, 1, kPF, PROD, RT>(w1h, w1l, t7h, t7l, X, lane, acc);
+      gemm_resident<kRes, 0, 1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc);
     else
-      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD, RT>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt, IE{}, IT{}, I0{}); });
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w1h, w1l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt, IE{}, IT{}, I0{}); });
     RBL_NSTAMP();  // 5: hidden gemm
     if constexpr (NH == 2) {
       // ------------------------------------------------------------ second hidden layer: the same half-resident scheme
       const f32x4* wt2 = w2 + (size_t)kRes * kOTW * 2 * 64 + fresh_t;
       fetch_tail(wt2, I0{}, IE{}, I0{});  // into the registers the first hidden layer's streamed k-steps just left
-      epilogue_regs(rt_tag, std::false_type{}, m.inv_scale[1], prm + 768);
-      init_acc(rt_tag, prm + 2 * 768);
-      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD, RT>(w2h, w2l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt2, IE{}, IT{}, I0{}); });
+      epilogue_regs(std::false_type{}, m.inv_scale[1], prm + 768);
+      init_acc(prm + 2 * 768);
+      gemm_hidden<kRes, kTail, kEarly, kE1, kPF, PROD>(w2h, w2l, t7h, t7l, X, lane, acc, [&]() { fetch_tail(wt2, IE{}, IT{}, I0{}); });
     }
     if (kEarlyStage) {
       // the next group's queries (requested a whole group ago) become B fragments now: Xq was last read by this group's layer-0
@@ -794,19 +765,18 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
       fetch_queries(grp + 2 * (int)gridDim.x);
     }
     RBL_NSTAMP();  // 6
-    epilogue_regs(rt_tag, std::true_type{}, m.inv_scale[NH], prm + NH * 768);
+    epilogue_regs(std::true_type{}, m.inv_scale[NH], prm + NH * 768);
     RBL_NSTAMP();  // 7: hidden epilogue (+ output tile 0 partials)
     // with three or four input chunks (48 / 64 KB per CU) the request goes out AFTER the output stores below: VMEM issues in
     // order, and behind 64 KB of weight loads the stores (and the waves issuing them) waited ~2 k cycles
     if constexpr (!kW0Late)
-      if (grp + (int)gridDim.x < n_items) fetch_w0();
+      if (grp + (int)gridDim.x < n_groups) fetch_w0();
 
     // -------------------------------------------------------------- register tiles: sum the 8 k slices of (tile, row tile)
     {
       const int n_reg = m.out_tiles < NOT ? m.out_tiles : NOT;
       for (int p = wave; p < n_reg * kRT; p += kWaves) {
         const int t = p >> 2, rt = p & 3;
-        if (rt >= RT) continue;
         const f32x4* pt = t == 0 ? P : X + (size_t)(t - 1) * kWaves * kRT * 64;
         f32x4 o = pt[(0 * kRT + rt) * 64 + lane];
 #pragma unroll
@@ -815,7 +785,7 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
         int r_in = rt * 16 + j, col = t * 16 + 4 * g;
         const int n_out = m.n_out;
         asm volatile("" : "+v"(r_in), "+v"(col));  // computed here, every group: hoisted copies cost spills
-        const int rows_here = (int)(rows - row0 < RT * 16 ? rows - row0 : RT * 16);
+        const int rows_here = (int)(rows - row0 < kRows ? rows - row0 : kRows);
         float* og = out + row0 * n_out;
         const f32x4 r4 = o * m.inv_scale[NH + 1] + *reinterpret_cast<const f32x4*>(prm + kOutBias + col);
         if (r_in < rows_here) {
@@ -876,14 +846,8 @@ __global__ void __launch_bounds__(kWaves * 64, 1) mlp_resident_kernel(const MlpD
     if (NOTV > 1 && m.out_tiles > 1) lds_barrier();  // X and P change hands
     RBL_NSTAMP();  // 8: output layer
     if constexpr (kW0Late)
-      if (grp + (int)gridDim.x < n_items) fetch_w0();
-  };
-  using RTFull = std::integral_constant<int, kRT>;
-  using RTHalf = std::integral_constant<int, kRT / 2>;
-  int it = blockIdx.x;
-  for (const int n_full = n_items < half_from ? n_items : half_from; it < n_full; it += gridDim.x, ++group_no) run_item(RTFull{}, it);
-  if constexpr (TAIL)
-    if (it < n_items) run_item(RTHalf{}, it);  // this workgroup's half of a group of the last round
+      if (grp + (int)gridDim.x < n_groups) fetch_w0();
+  }
   if (dbg_end && tid == 0) dbg_end[12] = (long long)clock64();  // whole workgroup: (this - stamp 0) / groups = steady state
 #undef RBL_NSTAMP
 }
@@ -910,19 +874,9 @@ void launch_mlp_resident(const MlpDev& m, const float* queries, int64_t rows, fl
   const int n_groups = (int)((rows + kRows - 1) / kRows);
   const int cap = m.grid_cap > 0 && m.grid_cap < cus ? m.grid_cap : cus;
   const int grid = n_groups < cap ? n_groups : cap;
-  const int grid_tail = 2 * n_groups < cap ? 2 * n_groups : cap;  // (a launch of few groups is all 32-row items)
-#define RBL_RES4(K0C_, LN_, NOT_, PROD_, NH_)                                                                                     \
-  do {                                                                                                                            \
-    if constexpr (K0C_ <= 2 && NOT_ == 1 && NH_ == 1) {                                                                           \
-      if (m.tail_items) {                                                                                                         \
-        RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_, NH_, true>), dim3(grid_tail), dim3(kWaves * 64), 0, stream, \
-                         m, queries, rows, out, n_groups, range);                                                                 \
-        break;                                                                                                                    \
-      }                                                                                                                           \
-    }                                                                                                                             \
-    RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_, NH_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries,    \
-                     rows, out, n_groups, range);                                                                                 \
-  } while (0)
+#define RBL_RES4(K0C_, LN_, NOT_, PROD_, NH_)                                                                                  \
+  RBL_LAUNCH_TIMED((mlp_resident_kernel<K0C_, LN_, NOT_, PROD_, NH_>), dim3(grid), dim3(kWaves * 64), 0, stream, m, queries, \
+                   rows, out, n_groups, range)
   // two hidden layers (n_layers = 3): built for one or two input chunks (every one-die game and 2 dice x 3 faces)
 #define RBL_RES3(K0C_, LN_, NOT_, PROD_)                                                                      \
   do {                                                                                                        \

@@ -21,13 +21,12 @@ from rebel_amd.models import Net2, mlp_weights_from_state_dict  # noqa: E402
 dice, faces = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 4)
 torch.manual_seed(0)
 net = Net2(num_faces=faces, num_dice=dice, n_hidden=256, use_layer_norm=True, n_layers=2).eval()
-for cap, tail in ((192, 0), (192, 1), (0, 0)):
+for cap in (192, 0):
     os.environ["RBL_NET_GRID"] = str(cap)
-    os.environ["RBL_NET_TAIL"] = str(tail)
     e = capi.Engine(dice, faces, capi.make_params(num_iters=4, use_cfr=True, max_depth=2))
     e.set_net_mlp(*mlp_weights_from_state_dict(net.state_dict()))
     grid = cap or 256
-    print(f"== {dice}d x {faces}f, grid cap {grid} workgroups (64-row groups, one persistent workgroup per CU), 32-row tail items {'on' if tail else 'off'}")
+    print(f"== {dice}d x {faces}f, grid cap {grid} workgroups (64-row groups, one persistent workgroup per CU)")
     print("  groups  per-WG  rows     us/launch   first group (cycles)  cycles/group over the workgroup   workgroup total")
     fine = len(sys.argv) > 3 and sys.argv[3] == "fine"
     sweep = (1.75, 2.0, 2.1, 2.25, 2.46, 2.6, 2.75, 2.9, 3.0, 3.1, 3.25, 3.5) if fine else (0.5, 1.0, 1.8, 2.0, 2.46, 3.0, 4.0, 8.0, 36.0)

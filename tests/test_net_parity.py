@@ -263,51 +263,3 @@ def test_half_inference_edge_batches():
     for rows in (1, 63, 64 * 256 + 1):
         for mode in (1, 2):
             _check_mlp(1, 6, 256, 2, True, rows, precision=mode, atol=3e-3)
-
-
-@pytest.mark.parametrize("d,f,precision", [(1, 4, 0), (1, 6, 0), (2, 3, 0), (1, 6, 1), (1, 6, 2)])
-def test_tail_items_give_bit_identical_rows(d, f, precision, monkeypatch):
-    """The persistent forward's 32-row tail items (MlpDev::tail_items; the engine turns them on for small interleaved lane parts)
-    change which workgroup computes a row and in how large a tile, not one bit of its arithmetic: with the grid capped at 8
-    workgroups, launches whose last round is 1-4 groups (split into halves), 5-8 groups (not split), a single partial group and
-    ragged ends equal the tail-less forward exactly -- and the float64 restatement of Net2 within the usual tolerance."""
-    from rebel_amd import capi
-
-    rng = np.random.default_rng(7 + 10 * d + f)
-    nets = None
-    outs = {}
-    # (rows): G = ceil(rows / 64) groups on W = 8 workgroups; halves when the last round holds at most 4 groups
-    sweep = [1, 31, 32, 33, 63, 64, 65, 100, 256, 257, 8 * 64 + 1, 8 * 64 + 4 * 64, 8 * 64 + 4 * 64 + 1, 16 * 64 + 3 * 64 + 17,
-             16 * 64 + 5 * 64, 24 * 64 + 31, 24 * 64 + 33, 5000]
-    for tail in ("0", "1"):
-        monkeypatch.setenv("RBL_NET_GRID", "8")
-        monkeypatch.setenv("RBL_NET_TAIL", tail)
-        e = capi.Engine(d, f, capi.make_params(num_iters=4, use_cfr=True))
-        e.set_net_precision(precision)
-        Q, H = e.Q, e.H
-        if nets is None:
-            layers = [(rng.uniform(-1, 1, (256, Q)).astype(np.float32) / np.sqrt(Q), rng.uniform(-0.1, 0.1, 256).astype(np.float32)),
-                      (rng.uniform(-1, 1, (256, 256)).astype(np.float32) / 16, rng.uniform(-0.1, 0.1, 256).astype(np.float32))]
-            ln = [(rng.uniform(0.5, 1.5, 256).astype(np.float32), rng.uniform(-0.2, 0.2, 256).astype(np.float32)) for _ in range(2)]
-            w_out = rng.uniform(-1, 1, (H, 256)).astype(np.float32) / 16
-            b_out = rng.uniform(-0.1, 0.1, H).astype(np.float32)
-            q = np.zeros((max(sweep), Q), np.float32)
-            q[:, 0] = rng.integers(0, 2, len(q))
-            q[np.arange(len(q)), 2 + rng.integers(0, e.A, len(q))] = 1
-            q[:, 2 + e.A:2 + e.A + H] = rng.dirichlet(np.ones(H), len(q))
-            q[:, 2 + e.A + H:] = rng.dirichlet(np.ones(H), len(q))
-            nets = (layers, ln, w_out, b_out, q)
-        layers, ln, w_out, b_out, q = nets
-        e.set_net_mlp(layers, ln, w_out, b_out)
-        assert e.stats()["net_kernel"] == 5
-        for rows in sweep:
-            outs[(tail, rows)] = e.net_forward(q[:rows])
-        e.close()
-    ref = _np_net(q, layers, ln, w_out, b_out)
-    for rows in sweep:
-        a, b = outs[("0", rows)], outs[("1", rows)]
-        assert np.array_equal(a, b), (rows, np.abs(a - b).max())
-        if precision == 0:
-            assert np.abs(b - ref[:rows]).max() <= ATOL
-        # every row is the same whatever the launch it was part of (a row's arithmetic does not depend on its tile)
-        assert np.array_equal(b, outs[("1", max(sweep))][:rows])
