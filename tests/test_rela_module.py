@@ -48,6 +48,80 @@ def test_surface_matches_reference(ours, ref_rela):
         assert a == b, cls
 
 
+def test_every_signature_matches_the_reference_module(ours, ref_rela):
+    """Beyond names: the pybind11 signature line of every public function, constructor and method (argument names, order, types,
+    return type) equals the compiled reference module's, module prefix aside -- so every positional and every keyword call the
+    unmodified trainer makes (cfvpy/selfplay.py:182-260: `ValuePrioritizedReplay(capacity=..., seed=..., alpha=..., beta=...,
+    prefetch=..., use_priority=..., compressed_values=...)`, `create_cfr_thread(model_locker, replay, cfg, seed)` ...) binds the
+    same way.  The one exception is DataThreadLoop's constructor: the reference exposes it with an argument type it never binds
+    (`rela::CVNetBufferConnector`), so it cannot be called from Python there either; ours has none."""
+    def sigs(m, prefix):
+        out = {}
+        for n in dir(m):
+            if n.startswith("_"):
+                continue
+            o = getattr(m, n)
+            members = [(n, o)] if not isinstance(o, type) else [
+                (f"{n}.{k}", getattr(o, k)) for k in dir(o) if k == "__init__" or not k.startswith("_")]
+            for name, f in members:
+                doc = (getattr(f, "__doc__", None) or "").strip().splitlines()
+                out[name] = doc[0].replace(prefix, "rela.") if doc else ""
+        return out
+
+    a, b = sigs(ours, "rebel_amd.rela."), sigs(ref_rela, "rela.")
+    assert set(a) == set(b)
+    for name in sorted(a):
+        if name == "DataThreadLoop.__init__":
+            assert "CVNetBufferConnector" in b[name]
+            continue
+        assert a[name] == b[name], name
+    assert "capacity" in a["ValuePrioritizedReplay.__init__"] and "model_locker" in a["create_cfr_thread"]
+
+
+def test_every_call_of_the_unmodified_trainer_binds(ours):
+    """tests/golden/trainer_rela_calls.json lists every call cfvpy/selfplay.py and cfvpy/utils.py make into `cfvpy.rela` (taken from
+    their syntax trees by tests/golden/make_trainer_calls.py: callee, positional count, keyword names incl. the keys of the
+    `replay_params` dictionary splatted into the replay's constructor).  Each must bind against this module's signature: enough
+    parameters for the positionals, every keyword a parameter name not already taken -- the static half of "the unmodified
+    trainer drives the module" (the dynamic half, the same call sequence on a GPU, is tests/test_rela_gpu.py)."""
+    import json
+    import re
+
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "trainer_rela_calls.json")))
+    assert len(fx["calls"]) >= 30
+
+    def params(callee):
+        obj = ours
+        for part in callee.split("."):
+            obj = getattr(obj, part)
+        f = obj.__init__ if isinstance(obj, type) else obj
+        sig = f.__doc__.strip().splitlines()[0]
+        inner = sig[sig.index("(") + 1:sig.rindex(") ->")]
+        names = [a.split(":")[0].strip() for a in re.split(r",\s*(?![^\[]*\])", inner) if a.strip()]
+        return names[1:] if names and names[0] == "self" else names
+
+    seen = set()
+    for c in fx["calls"]:
+        names = params(c["callee"])
+        kw = c["keywords"] + c["star_kwargs_keys"]
+        assert c["n_positional"] <= len(names), c
+        free = names[c["n_positional"]:]
+        assert all(k in free for k in kw) and len(set(kw)) == len(kw), (c, names)
+        if c["callee"] in ("ValuePrioritizedReplay", "create_cfr_thread", "ModelLocker", "ValuePrioritizedReplay.load"):
+            assert c["n_positional"] + len(kw) == len(names), (c, names)  # no defaults in the reference's bindings: all given
+        seen.add(c["callee"])
+    assert {"ModelLocker", "ValuePrioritizedReplay", "create_cfr_thread", "Context.push_env_thread", "Context.start",
+            "Context.terminate", "ModelLocker.update_model", "ValuePrioritizedReplay.sample", "ValuePrioritizedReplay.pop_until",
+            "ValuePrioritizedReplay.load", "ValuePrioritizedReplay.save", "compute_stats_with_net", "RecursiveSolvingParams"} <= seen
+    # cfvpy/utils.py subclasses rela.Context (TimedContext): the class must be subclassable from Python
+    assert [b["base"] for b in fx["subclasses"]] == ["Context"]
+
+    class Sub(ours.Context):
+        pass
+
+    assert isinstance(Sub(), ours.Context)
+
+
 def test_param_defaults_and_nested_setattr(ours):
     sp = ours.SubgameSolvingParams()  # subgame_solving.h:43-58
     assert (sp.num_iters, sp.max_depth, sp.linear_update, sp.use_cfr, sp.optimistic, sp.dcfr) == (10, 2, False, False,
